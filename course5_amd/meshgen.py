@@ -1,0 +1,184 @@
+"""Deterministic synthetic tetrahedral grids and legacy-VTK writers (host tooling).
+
+The reference ships no data files (`/root/reference/.gitignore:3-4` excludes *.vtk / *.vti), so
+every grid used by tests and by `bench.py` is generated here from fixed seeds.  The on-disk
+contract is the one the reference reads (`project/src/object3d_base.cpp:13-53`,
+`object3d_accretion_disk.cpp:4`): legacy VTK `DATASET UNSTRUCTURED_GRID`, all cells
+tetrahedra, CELL_DATA scalars named `AbsorpCoef` and `radEnLooseRate`.
+
+Workloads follow SURVEY.md §8(d):
+  C1  cube8()                 8 tets, 9 points, inside the hard-coded domain
+  C2  ball(n=36, r=0.45)      ~107k tets, non-convex staircase boundary
+  C3  kuhn_box(n=55)          998 250 tets, 175 616 points
+"""
+from __future__ import annotations
+
+import itertools
+
+import numpy as np
+
+# Domain of the reference, in its own order {x_max, x_min, y_max, y_min} (main.cpp:83).
+REFERENCE_BOUNDS = (2.2, -0.2, 0.9, -0.9)
+# View used for every benchmark configuration (generic: avoids pixel/vertex alignment).
+BENCH_VIEW = dict(angle_around_x=0.1, angle_around_y=0.07, initial_system_angle=0.0)
+
+
+def signed_volumes(xyz: np.ndarray, cells: np.ndarray) -> np.ndarray:
+    p = xyz[cells]  # [n,4,3]
+    a = p[:, 1] - p[:, 0]
+    b = p[:, 2] - p[:, 0]
+    c = p[:, 3] - p[:, 0]
+    return np.einsum("ij,ij->i", a, np.cross(b, c)) / 6.0
+
+
+def orient_positive(xyz: np.ndarray, cells: np.ndarray) -> np.ndarray:
+    """Swap the last two vertices of negatively oriented cells (in place on a copy)."""
+    cells = cells.copy()
+    neg = signed_volumes(xyz, cells) < 0
+    cells[neg, 2], cells[neg, 3] = cells[neg, 3].copy(), cells[neg, 2].copy()
+    return cells
+
+
+def validate(xyz: np.ndarray, cells: np.ndarray, min_rel_volume: float = 1e-6) -> None:
+    """Reject meshes a face-adjacency walk (or the reference's pairing) cannot handle."""
+    vol = signed_volumes(xyz, cells)
+    if not np.all(np.isfinite(vol)):
+        raise ValueError("non-finite cell volume")
+    scale = np.abs(vol).mean()
+    if np.any(vol <= min_rel_volume * scale):
+        raise ValueError(f"{int((vol <= min_rel_volume * scale).sum())} inverted or degenerate cells")
+
+
+def scalars(n_cells: int, seed: int = 1234) -> tuple[np.ndarray, np.ndarray]:
+    """alpha ~ U[0,4) (exercises the 2.5 clamp), Q ~ U[0,1)  (SURVEY §8(d))."""
+    rng = np.random.default_rng(seed)
+    alpha = rng.uniform(0.0, 4.0, n_cells)
+    q = rng.uniform(0.0, 1.0, n_cells)
+    return alpha, q
+
+
+def cube8(lo=(0.5, -0.5, -0.5), size: float = 1.0):
+    """Five-tet split of a cube whose central tet is split at its centroid: 8 tets, 9 points."""
+    corners = np.array(list(itertools.product((0.0, 1.0), repeat=3)))  # id = 4x+2y+z
+    vid = lambda x, y, z: 4 * x + 2 * y + z  # noqa: E731
+    even = [vid(0, 0, 0), vid(1, 1, 0), vid(1, 0, 1), vid(0, 1, 1)]
+    corner_tets = [
+        [vid(1, 0, 0), vid(0, 0, 0), vid(1, 1, 0), vid(1, 0, 1)],
+        [vid(0, 1, 0), vid(0, 0, 0), vid(1, 1, 0), vid(0, 1, 1)],
+        [vid(0, 0, 1), vid(0, 0, 0), vid(1, 0, 1), vid(0, 1, 1)],
+        [vid(1, 1, 1), vid(1, 1, 0), vid(1, 0, 1), vid(0, 1, 1)],
+    ]
+    centre = corners[even].mean(axis=0)
+    pts = np.vstack([corners, centre])
+    c = 8
+    central = [[c, even[0], even[1], even[2]], [c, even[0], even[1], even[3]],
+               [c, even[0], even[2], even[3]], [c, even[1], even[2], even[3]]]
+    cells = np.array(corner_tets + central, dtype=np.int32)
+    xyz = np.asarray(lo, dtype=np.float64) + size * pts
+    cells = orient_positive(xyz, cells)
+    validate(xyz, cells)
+    return xyz, cells
+
+
+_KUHN_PERMS = list(itertools.permutations(range(3)))
+
+
+def kuhn_box(n: int, lo=(0.5, -0.5, -0.5), size: float = 1.0, jitter: float = 0.0, seed: int = 1234,
+             keep=None):
+    """n^3 cubes x 6 Kuhn tets (conforming).  Interior points get uniform jitter <= jitter*h.
+
+    keep: optional callable(centroids[n_cells,3]) -> bool mask selecting cells to keep
+    (points are compacted afterwards).
+    """
+    h = size / n
+    m = n + 1
+    g = np.arange(m)
+    ii, jj, kk = np.meshgrid(g, g, g, indexing="ij")
+    xyz = np.stack([ii, jj, kk], axis=-1).reshape(-1, 3).astype(np.float64) * h
+    if jitter > 0:
+        rng = np.random.default_rng(seed)
+        d = rng.uniform(-jitter * h, jitter * h, xyz.shape)
+        interior = ((ii > 0) & (ii < n) & (jj > 0) & (jj < n) & (kk > 0) & (kk < n)).reshape(-1)
+        xyz[interior] += d[interior]
+    xyz += np.asarray(lo, dtype=np.float64)
+
+    ci, cj, ck = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    base = np.stack([ci, cj, ck], axis=-1).reshape(-1, 3)  # [n^3,3]
+    pid = lambda c: (c[:, 0] * m + c[:, 1]) * m + c[:, 2]  # noqa: E731
+    cells = []
+    for perm in _KUHN_PERMS:
+        v = [base.copy()]
+        for axis in perm:
+            nxt = v[-1].copy()
+            nxt[:, axis] += 1
+            v.append(nxt)
+        cells.append(np.stack([pid(c) for c in v], axis=1))
+    cells = np.stack(cells, axis=1).reshape(-1, 4).astype(np.int32)  # cube-major, 6 per cube
+
+    if keep is not None:
+        mask = keep(xyz[cells].mean(axis=1))
+        cells = cells[mask]
+        used = np.unique(cells)
+        remap = np.full(xyz.shape[0], -1, dtype=np.int64)
+        remap[used] = np.arange(used.size)
+        xyz = xyz[used]
+        cells = remap[cells].astype(np.int32)
+
+    cells = orient_positive(xyz, cells)
+    validate(xyz, cells)
+    return xyz, cells
+
+
+def ball(n: int = 36, r: float = 0.45, centre=(1.0, 0.0, 0.0), jitter: float = 0.1, seed: int = 1234):
+    """Kuhn box cells whose centroid lies within r of centre: non-convex staircase boundary (C2)."""
+    c = np.asarray(centre, dtype=np.float64)
+    return kuhn_box(n, jitter=jitter, seed=seed,
+                    keep=lambda cen: np.linalg.norm(cen - c, axis=1) < r)
+
+
+def workload(name: str):
+    """Named benchmark / test grids -> (xyz, cells, alpha, q)."""
+    if name == "c1":
+        xyz, cells = cube8()
+    elif name == "g2":  # 4^3 Kuhn grid, 384 tets
+        xyz, cells = kuhn_box(4, jitter=0.1)
+    elif name == "c2":
+        xyz, cells = ball(36, 0.45)
+    elif name == "c3":
+        xyz, cells = kuhn_box(55, jitter=0.1)
+    elif name.startswith("kuhn"):
+        xyz, cells = kuhn_box(int(name[4:]), jitter=0.1)
+    else:
+        raise ValueError(f"unknown workload {name!r}")
+    alpha, q = scalars(cells.shape[0])
+    return xyz, cells, alpha, q
+
+
+def view_rotations(angle_around_x: float = 0.0, angle_around_y: float = 0.0,
+                   initial_system_angle: float = 0.0, x0: float = 1.0) -> np.ndarray:
+    """Rotation list [n,3] = {axis (0 = x, 1 = y), angle, x0} applied to the grid by `course`.
+
+    Mirrors `/root/reference/project/src/main.cpp:96,105-107`; angles are in units of pi.
+    """
+    pi = 3.14159265358979323846  # config.hpp:45
+    mp = -initial_system_angle * pi + pi / 2.0
+    return np.array([[0.0, mp, 0.0],
+                     [1.0, angle_around_y * pi, x0],
+                     [0.0, -mp + angle_around_x * pi, 0.0]], dtype=np.float64)
+
+
+def write_vtk_ascii(path: str, xyz: np.ndarray, cells: np.ndarray, alpha: np.ndarray, q: np.ndarray) -> None:
+    """Legacy ASCII VTK unstructured grid with the two cell scalars the reference reads."""
+    n_pts, n_cells = xyz.shape[0], cells.shape[0]
+    with open(path, "w") as f:
+        f.write("# vtk DataFile Version 3.0\nsynthetic tetrahedral grid\nASCII\nDATASET UNSTRUCTURED_GRID\n")
+        f.write(f"POINTS {n_pts} double\n")
+        np.savetxt(f, xyz, fmt="%.17g")
+        f.write(f"CELLS {n_cells} {5 * n_cells}\n")
+        np.savetxt(f, np.hstack([np.full((n_cells, 1), 4, dtype=np.int64), cells.astype(np.int64)]), fmt="%d")
+        f.write(f"CELL_TYPES {n_cells}\n")
+        np.savetxt(f, np.full(n_cells, 10, dtype=np.int64), fmt="%d")
+        f.write(f"CELL_DATA {n_cells}\n")
+        for name, arr in (("AbsorpCoef", alpha), ("radEnLooseRate", q)):
+            f.write(f"SCALARS {name} double 1\nLOOKUP_TABLE default\n")
+            np.savetxt(f, arr, fmt="%.17g")
