@@ -1,0 +1,18 @@
+// Face adjacency of a conforming tetrahedral grid (host side, run once per upload).
+// The reference discards connectivity (object3d_base.cpp:13-53 copies points per cell);
+// the walk needs it, so it is rebuilt here from the cell -> point-id table.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace c5 {
+
+// adj[4 * cell + f] = neighbour across face f (reference face numbering: 0 = (0,1,2),
+// 1 = (0,1,3), 2 = (0,2,3), 3 = (1,2,3)) or -1; bfaces = (cell << 2 | f) of faces without one.
+// Returns false (and a message) if a face is shared by more than two cells or an id is out of range.
+bool build_face_adjacency(const int32_t* cell_vert, int64_t n_cells, int64_t n_pts,
+                          std::vector<int32_t>& adj, std::vector<uint32_t>& bfaces, std::string& err);
+
+}  // namespace c5

@@ -1,0 +1,721 @@
+// C ABI (include/course5_hip.h) of the MI355X render path: context, device buffers and the
+// per-frame kernel sequence.  No exceptions cross the ABI; every entry point returns a status
+// and leaves a message for c5_last_error().
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/course5_hip.h"
+#include "adjacency.hpp"
+#include "device_types.hpp"
+#include "kernels.hpp"
+
+namespace {
+
+std::string g_create_error;
+
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t want) {
+        if (want <= bytes && ptr) return hipSuccess;
+        if (ptr) {
+            hipError_t e = hipFree(ptr);
+            ptr = nullptr;
+            bytes = 0;
+            if (e != hipSuccess) return e;
+        }
+        if (want == 0) return hipSuccess;
+        hipError_t e = hipMalloc(&ptr, want);
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+    template <class T>
+    T* as() const {
+        return static_cast<T*>(ptr);
+    }
+};
+
+struct Solid {
+    int64_t n_tets = 0;
+    double colour = 0.0;
+    DeviceBuffer raw, view;  // [n][4][3] doubles
+    c5::RotationList rots{};
+};
+
+constexpr int kWalkEventPool = 512;
+
+}  // namespace
+
+struct c5_context {
+    int device = 0;
+    hipStream_t stream = nullptr;      // stream in use
+    hipStream_t own_stream = nullptr;  // created by c5_create
+    std::string error;
+
+    // persistent grid
+    int64_t n_pts = 0, n_cells = 0, n_bfaces = 0;
+    DeviceBuffer px, py, pz, vx, vy, vz, cell_vert, cell_adj, alpha, q, bface, rec, opt;
+    c5::RotationList view{};
+    Solid solids[C5_MAX_SOLIDS];
+
+    // image
+    bool have_image = false;
+    double bounds[4] = {0, 0, 0, 0};
+    c5::ImageParams im{};
+    int cfg_tile_rows = 0, cfg_rank = 0, cfg_world = 1;
+    DeviceBuffer xtab, ytab, count, offs, scratch, entries, mask, out, counters;
+    int64_t entry_capacity = 0;
+    c5::FrameCounters* host_counters = nullptr;  // pinned
+
+    // options
+    double alpha_limit = 2.5;
+    double t_cutoff = 1e-12;
+    int tile_shape = 0;
+    int xcd_mode = 1;
+    int order = 0;
+    int stage_timing = 1;
+    int walk_timing = 1;
+
+    // events
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t walk_a[kWalkEventPool];
+    hipEvent_t walk_b[kWalkEventPool];
+    int walk_used = 0;
+    double walk_ms_sum = 0.0;
+    int64_t walk_launches = 0;
+
+    bool using_caller_stream = false;
+    bool frame_pending = false;
+    bool frame_timed = false;
+    c5_stats last{};
+};
+
+namespace {
+
+int fail(c5_context* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->error = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+#define C5_HIP(ctx, expr)                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail((ctx), C5_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                     \
+    } while (0)
+
+int bind_device(c5_context* ctx) {
+    C5_HIP(ctx, hipSetDevice(ctx->device));
+    return C5_OK;
+}
+
+int to_rotation_list(c5_context* ctx, const c5_rotation* rots, int n, c5::RotationList& out) {
+    if (n < 0 || n > C5_MAX_ROTATIONS) return fail(ctx, C5_ERR_INVALID, "rotation count %d out of range", n);
+    if (n > 0 && !rots) return fail(ctx, C5_ERR_INVALID, "null rotation list");
+    out.n = n;
+    for (int k = 0; k < n; ++k) {
+        if (rots[k].axis != 0 && rots[k].axis != 1)
+            return fail(ctx, C5_ERR_INVALID, "rotation axis must be 0 (x) or 1 (y)");
+        out.axis[k] = rots[k].axis;
+        // libm on the host, like tetra.cpp:46-47,58-59
+        out.cosv[k] = std::cos(rots[k].angle);
+        out.sinv[k] = std::sin(rots[k].angle);
+        out.x0[k] = rots[k].x0;
+    }
+    return C5_OK;
+}
+
+int recompute_rows(c5_context* ctx) {
+    c5::ImageParams& im = ctx->im;
+    im.tile_rows = (ctx->cfg_tile_rows > 0) ? ctx->cfg_tile_rows : (im.res_y > 0 ? im.res_y : 1);
+    im.rank = ctx->cfg_rank;
+    im.world = ctx->cfg_world;
+    int n = 0;
+    for (int r = 0; r < im.res_y; ++r)
+        if (c5::local_row_of(im, r) >= 0) ++n;
+    im.n_local_rows = n;
+    return C5_OK;
+}
+
+int ensure_image_buffers(c5_context* ctx) {
+    const c5::ImageParams& im = ctx->im;
+    const int64_t n_px = static_cast<int64_t>(im.n_local_rows) * im.res_x;
+    const int64_t padded = ((n_px + 1023) / 1024) * 1024;
+    C5_HIP(ctx, ctx->count.ensure(static_cast<size_t>(padded + 1024) * sizeof(int32_t)));
+    C5_HIP(ctx, ctx->offs.ensure(static_cast<size_t>(padded + 1024) * sizeof(int32_t)));
+    C5_HIP(ctx, ctx->scratch.ensure(static_cast<size_t>(padded / 1024 + 1024) * sizeof(int32_t)));
+    C5_HIP(ctx, ctx->mask.ensure(static_cast<size_t>(padded) * sizeof(uint32_t)));
+    C5_HIP(ctx, ctx->out.ensure(static_cast<size_t>(padded) * sizeof(float) * 2));
+    if (ctx->entry_capacity < 2 * n_px + 1024) {
+        ctx->entry_capacity = 2 * n_px + 1024;
+        C5_HIP(ctx, ctx->entries.ensure(static_cast<size_t>(ctx->entry_capacity) * sizeof(c5::Entry)));
+    }
+    return C5_OK;
+}
+
+// Enqueue one frame on the context's stream; the image goes to out_dev.
+int enqueue_frame(c5_context* ctx, float2* out_dev) {
+    if (ctx->n_cells <= 0 && [&] {
+            for (const Solid& s : ctx->solids)
+                if (s.n_tets > 0) return false;
+            return true;
+        }())
+        return fail(ctx, C5_ERR_STATE, "plane initializer. empty set of objects to render");  // plane.cpp:269-271
+    if (!ctx->have_image) return fail(ctx, C5_ERR_STATE, "critical error. empty plane");  // plane.cpp:151-153
+    int rc = bind_device(ctx);
+    if (rc) return rc;
+    rc = ensure_image_buffers(ctx);
+    if (rc) return rc;
+
+    hipStream_t s = ctx->stream;
+    const c5::ImageParams& im = ctx->im;
+    const int64_t n_px = static_cast<int64_t>(im.n_local_rows) * im.res_x;
+    const int64_t padded = ((n_px + 1023) / 1024) * 1024;
+    const bool timed = ctx->stage_timing != 0;
+    auto mark = [&](int k) -> hipError_t { return timed ? hipEventRecord(ctx->ev[k], s) : hipSuccess; };
+
+    C5_HIP(ctx, mark(0));
+    C5_HIP(ctx, hipMemsetAsync(ctx->counters.ptr, 0, sizeof(c5::FrameCounters), s));
+
+    c5::GridView g;
+    g.n_pts = ctx->n_pts;
+    g.n_cells = ctx->n_cells;
+    g.n_bfaces = ctx->n_bfaces;
+    g.px = ctx->px.as<double>();
+    g.py = ctx->py.as<double>();
+    g.pz = ctx->pz.as<double>();
+    g.vx = ctx->vx.as<double>();
+    g.vy = ctx->vy.as<double>();
+    g.vz = ctx->vz.as<double>();
+    g.cell_vert = ctx->cell_vert.as<int4>();
+    g.cell_adj = ctx->cell_adj.as<int4>();
+    g.alpha = ctx->alpha.as<double>();
+    g.q = ctx->q.as<double>();
+    g.bface = ctx->bface.as<uint32_t>();
+    g.rec = ctx->rec.as<c5::CellRecord>();
+    g.opt = ctx->opt.as<c5::CellOptics>();
+
+    // (a2) view transform
+    c5::launch_transform_soa(s, g.px, g.py, g.pz, g.vx, g.vy, g.vz, g.n_pts, ctx->view);
+    C5_HIP(ctx, mark(1));
+    // (a1, a10, a13 constants) per-cell records
+    c5::launch_build_records(s, g, ctx->alpha_limit);
+    C5_HIP(ctx, mark(2));
+    // boundary entries: count -> scan -> fill
+    C5_HIP(ctx, hipMemsetAsync(ctx->count.ptr, 0, static_cast<size_t>(padded + 1) * sizeof(int32_t), s));
+    if (g.n_cells > 0) {
+        c5::launch_entry_count(s, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im, ctx->count.as<int32_t>(),
+                                ctx->order != 0);
+    }
+    c5::launch_exclusive_scan(s, ctx->count.as<int32_t>(), ctx->offs.as<int32_t>(), n_px,
+                              ctx->scratch.as<int32_t>(), ctx->counters.as<c5::FrameCounters>());
+    if (g.n_cells > 0) {
+        c5::launch_entry_fill(s, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im, ctx->count.as<int32_t>(),
+                              ctx->offs.as<int32_t>(), ctx->entries.as<c5::Entry>(), ctx->entry_capacity,
+                              ctx->counters.as<c5::FrameCounters>(), ctx->order != 0);
+    }
+    C5_HIP(ctx, mark(3));
+    // (a9) solids
+    c5::SolidTable table{};
+    bool any_solid = false;
+    uint32_t next_id = 0;
+    for (int k = 0; k < C5_MAX_SOLIDS; ++k) {
+        table.first_id[k] = next_id;
+        table.colour[k] = ctx->solids[k].colour;
+        if (ctx->solids[k].n_tets > 0) {
+            any_solid = true;
+            next_id += static_cast<uint32_t>(ctx->solids[k].n_tets);
+        }
+    }
+    table.first_id[C5_MAX_SOLIDS] = next_id;
+    table.n_slots = C5_MAX_SOLIDS;
+    if (any_solid) {
+        C5_HIP(ctx, hipMemsetAsync(ctx->mask.ptr, 0, static_cast<size_t>(padded) * sizeof(uint32_t), s));
+        for (int k = 0; k < C5_MAX_SOLIDS; ++k) {
+            Solid& so = ctx->solids[k];
+            if (so.n_tets <= 0) continue;
+            c5::launch_transform_aos(s, so.raw.as<double>(), so.view.as<double>(), 4 * so.n_tets, so.rots);
+            c5::launch_solid_mask_raster(s, so.view.as<double>(), so.n_tets, table.first_id[k],
+                                         ctx->ytab.as<double>(), im, ctx->mask.as<uint32_t>());
+        }
+    }
+    C5_HIP(ctx, mark(4));
+
+    // (a11-a14) walk
+    c5::WalkParams wp{};
+    wp.rec = g.rec;
+    wp.opt = g.opt;
+    wp.entry_offs = ctx->offs.as<int32_t>();
+    wp.entries = ctx->entries.as<c5::Entry>();
+    wp.mask = any_solid ? ctx->mask.as<uint32_t>() : nullptr;
+    wp.solids = table;
+    wp.Xtab = ctx->xtab.as<double>();
+    wp.Ytab = ctx->ytab.as<double>();
+    wp.out = out_dev;
+    wp.im = im;
+    wp.t_cutoff = ctx->t_cutoff;
+    wp.max_steps = static_cast<uint32_t>(ctx->n_cells + 64);
+    wp.xcd_mode = ctx->xcd_mode;
+    wp.order = ctx->order;
+    wp.counters = ctx->counters.as<c5::FrameCounters>();
+
+    int slot = -1;
+    if (ctx->walk_timing) {
+        if (ctx->walk_used == kWalkEventPool) {  // fold the pool before reusing it
+            for (int k = 0; k < kWalkEventPool; ++k) {
+                C5_HIP(ctx, hipEventSynchronize(ctx->walk_b[k]));
+                float ms = 0.f;
+                C5_HIP(ctx, hipEventElapsedTime(&ms, ctx->walk_a[k], ctx->walk_b[k]));
+                ctx->walk_ms_sum += ms;
+            }
+            ctx->walk_launches += kWalkEventPool;
+            ctx->walk_used = 0;
+        }
+        slot = ctx->walk_used++;
+        C5_HIP(ctx, hipEventRecord(ctx->walk_a[slot], s));
+    }
+    c5::launch_walk(s, wp, ctx->tile_shape);
+    if (slot >= 0) C5_HIP(ctx, hipEventRecord(ctx->walk_b[slot], s));
+    C5_HIP(ctx, mark(5));
+    C5_HIP(ctx, hipGetLastError());
+
+    C5_HIP(ctx, hipMemcpyAsync(ctx->host_counters, ctx->counters.ptr, sizeof(c5::FrameCounters),
+                               hipMemcpyDeviceToHost, s));
+    ctx->frame_pending = true;
+    ctx->frame_timed = timed;
+    return C5_OK;
+}
+
+// After the stream drained: collect counters/timings; grow the entry buffer if it overflowed.
+int finish_frame(c5_context* ctx) {
+    if (!ctx->frame_pending) return C5_OK;
+    ctx->frame_pending = false;
+    const c5::FrameCounters& hc = *ctx->host_counters;
+    c5_stats& st = ctx->last;
+    st.segments = static_cast<int64_t>(hc.segments);
+    st.covered_pixels = static_cast<int64_t>(hc.covered);
+    st.solid_pixels = static_cast<int64_t>(hc.solid_pixels);
+    st.entries = static_cast<int64_t>(hc.entries);
+    st.boundary_faces = ctx->n_bfaces;
+    st.steps = static_cast<int64_t>(hc.steps);
+    st.walk_overflow = static_cast<int32_t>(hc.walk_overflow);
+    if (ctx->frame_timed) {
+        float* dst[5] = {&st.ms_transform, &st.ms_records, &st.ms_entries, &st.ms_solids, &st.ms_walk};
+        for (int k = 0; k < 5; ++k) C5_HIP(ctx, hipEventElapsedTime(dst[k], ctx->ev[k], ctx->ev[k + 1]));
+        C5_HIP(ctx, hipEventElapsedTime(&st.ms_total, ctx->ev[0], ctx->ev[5]));
+    }
+    if (hc.entry_overflow || static_cast<int64_t>(hc.entries) > ctx->entry_capacity) {
+        st.entry_overflow += 1;
+        ctx->entry_capacity = static_cast<int64_t>(hc.entries) + static_cast<int64_t>(hc.entries) / 4 + 1024;
+        C5_HIP(ctx, ctx->entries.ensure(static_cast<size_t>(ctx->entry_capacity) * sizeof(c5::Entry)));
+        return fail(ctx, C5_RETRY, "entry buffer grown to %lld records; render the frame again",
+                    static_cast<long long>(ctx->entry_capacity));
+    }
+    if (hc.walk_overflow)
+        return fail(ctx, C5_ERR_WALK, "%u rays exceeded the walk step bound (malformed grid?)", hc.walk_overflow);
+    return C5_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int c5_abi_version(void) { return C5_ABI_VERSION; }
+
+int c5_device_count(int* count) {
+    if (!count) return fail(nullptr, C5_ERR_INVALID, "null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(nullptr, C5_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return C5_OK;
+}
+
+int c5_create(int device_ordinal, c5_context** out_ctx) {
+    if (!out_ctx) return fail(nullptr, C5_ERR_INVALID, "null out_ctx");
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, C5_ERR_NO_DEVICE, "no HIP device available (%s)",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device_ordinal < 0 || device_ordinal >= n)
+        return fail(nullptr, C5_ERR_INVALID, "device ordinal %d out of range [0, %d)", device_ordinal, n);
+    c5_context* ctx = new (std::nothrow) c5_context();
+    if (!ctx) return fail(nullptr, C5_ERR_INVALID, "out of host memory");
+    ctx->device = device_ordinal;
+    auto bail = [&](hipError_t err, const char* what) {
+        fail(nullptr, C5_ERR_HIP, "%s: %s", what, hipGetErrorString(err));
+        c5_destroy(ctx);
+        return C5_ERR_HIP;
+    };
+    if ((e = hipSetDevice(device_ordinal)) != hipSuccess) return bail(e, "hipSetDevice");
+    if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess)
+        return bail(e, "hipStreamCreate");
+    ctx->stream = ctx->own_stream;
+    for (auto& ev : ctx->ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
+    for (int k = 0; k < kWalkEventPool; ++k) {
+        ctx->walk_a[k] = ctx->walk_b[k] = nullptr;
+    }
+    for (int k = 0; k < kWalkEventPool; ++k) {
+        if ((e = hipEventCreate(&ctx->walk_a[k])) != hipSuccess) return bail(e, "hipEventCreate");
+        if ((e = hipEventCreate(&ctx->walk_b[k])) != hipSuccess) return bail(e, "hipEventCreate");
+    }
+    if ((e = ctx->counters.ensure(sizeof(c5::FrameCounters))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->host_counters), sizeof(c5::FrameCounters),
+                           hipHostMallocDefault)) != hipSuccess)
+        return bail(e, "hipHostMalloc");
+    std::memset(ctx->host_counters, 0, sizeof(c5::FrameCounters));
+    ctx->view.n = 0;
+    for (Solid& s : ctx->solids) s.rots.n = 0;
+    *out_ctx = ctx;
+    return C5_OK;
+}
+
+void c5_destroy(c5_context* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DeviceBuffer* bufs[] = {&ctx->px, &ctx->py, &ctx->pz, &ctx->vx, &ctx->vy, &ctx->vz, &ctx->cell_vert,
+                            &ctx->cell_adj, &ctx->alpha, &ctx->q, &ctx->bface, &ctx->rec, &ctx->opt,
+                            &ctx->xtab, &ctx->ytab, &ctx->count, &ctx->offs, &ctx->scratch, &ctx->entries,
+                            &ctx->mask, &ctx->out, &ctx->counters};
+    for (DeviceBuffer* b : bufs) b->release();
+    for (Solid& s : ctx->solids) {
+        s.raw.release();
+        s.view.release();
+    }
+    if (ctx->host_counters) (void)hipHostFree(ctx->host_counters);
+    for (auto& ev : ctx->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    for (int k = 0; k < kWalkEventPool; ++k) {
+        if (ctx->walk_a[k]) (void)hipEventDestroy(ctx->walk_a[k]);
+        if (ctx->walk_b[k]) (void)hipEventDestroy(ctx->walk_b[k]);
+    }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int c5_set_stream(c5_context* ctx, void* hip_stream) {
+    if (!ctx) return fail(nullptr, C5_ERR_INVALID, "null context");
+    int rc = bind_device(ctx);
+    if (rc) return rc;
+    C5_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rc = finish_frame(ctx);
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    ctx->using_caller_stream = hip_stream != nullptr;
+    return rc == C5_RETRY ? C5_OK : rc;
+}
+
+const char* c5_last_error(const c5_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int32_t* cell_vert,
+                   int64_t n_cells, const double* alpha, const double* q) {
+    if (!ctx) return fail(nullptr, C5_ERR_INVALID, "null context");
+    if (n_pts < 0 || n_cells < 0) return fail(ctx, C5_ERR_INVALID, "negative size");
+    if (n_cells > 0 && (!xyz || !cell_vert || !alpha || !q)) return fail(ctx, C5_ERR_INVALID, "null grid array");
+    if (n_cells >= static_cast<int64_t>(c5::kNoCell))
+        return fail(ctx, C5_ERR_INVALID, "cell count %lld does not fit 28 bits (line.hpp:71-79)",
+                    static_cast<long long>(n_cells));
+    int rc = bind_device(ctx);
+    if (rc) return rc;
+
+    std::vector<int32_t> adj;
+    std::vector<uint32_t> bfaces;
+    std::string err;
+    if (!c5::build_face_adjacency(cell_vert, n_cells, n_pts, adj, bfaces, err))
+        return fail(ctx, err.find("range") != std::string::npos ? C5_ERR_INVALID : C5_ERR_MESH, "%s", err.c_str());
+
+    // SoA split of the points
+    std::vector<double> sx(static_cast<size_t>(n_pts)), sy(static_cast<size_t>(n_pts)), sz(static_cast<size_t>(n_pts));
+    for (int64_t i = 0; i < n_pts; ++i) {
+        sx[static_cast<size_t>(i)] = xyz[3 * i];
+        sy[static_cast<size_t>(i)] = xyz[3 * i + 1];
+        sz[static_cast<size_t>(i)] = xyz[3 * i + 2];
+    }
+    const size_t pb = static_cast<size_t>(n_pts) * sizeof(double);
+    const size_t cb = static_cast<size_t>(n_cells);
+    C5_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DeviceBuffer* pbufs[] = {&ctx->px, &ctx->py, &ctx->pz, &ctx->vx, &ctx->vy, &ctx->vz};
+    for (DeviceBuffer* b : pbufs) C5_HIP(ctx, b->ensure(pb ? pb : 8));
+    C5_HIP(ctx, ctx->cell_vert.ensure(cb * 16 + 16));
+    C5_HIP(ctx, ctx->cell_adj.ensure(cb * 16 + 16));
+    C5_HIP(ctx, ctx->alpha.ensure(cb * 8 + 8));
+    C5_HIP(ctx, ctx->q.ensure(cb * 8 + 8));
+    C5_HIP(ctx, ctx->bface.ensure(bfaces.size() * 4 + 4));
+    C5_HIP(ctx, ctx->rec.ensure(cb * sizeof(c5::CellRecord) + 128));
+    C5_HIP(ctx, ctx->opt.ensure(cb * sizeof(c5::CellOptics) + 32));
+    if (n_pts > 0) {
+        C5_HIP(ctx, hipMemcpy(ctx->px.ptr, sx.data(), pb, hipMemcpyHostToDevice));
+        C5_HIP(ctx, hipMemcpy(ctx->py.ptr, sy.data(), pb, hipMemcpyHostToDevice));
+        C5_HIP(ctx, hipMemcpy(ctx->pz.ptr, sz.data(), pb, hipMemcpyHostToDevice));
+    }
+    if (n_cells > 0) {
+        C5_HIP(ctx, hipMemcpy(ctx->cell_vert.ptr, cell_vert, cb * 16, hipMemcpyHostToDevice));
+        C5_HIP(ctx, hipMemcpy(ctx->cell_adj.ptr, adj.data(), cb * 16, hipMemcpyHostToDevice));
+        C5_HIP(ctx, hipMemcpy(ctx->alpha.ptr, alpha, cb * 8, hipMemcpyHostToDevice));
+        C5_HIP(ctx, hipMemcpy(ctx->q.ptr, q, cb * 8, hipMemcpyHostToDevice));
+    }
+    if (!bfaces.empty())
+        C5_HIP(ctx, hipMemcpy(ctx->bface.ptr, bfaces.data(), bfaces.size() * 4, hipMemcpyHostToDevice));
+    ctx->n_pts = n_pts;
+    ctx->n_cells = n_cells;
+    ctx->n_bfaces = static_cast<int64_t>(bfaces.size());
+    return C5_OK;
+}
+
+int c5_update_scalars(c5_context* ctx, const double* alpha, const double* q, int64_t n_cells) {
+    if (!ctx) return fail(nullptr, C5_ERR_INVALID, "null context");
+    if (n_cells != ctx->n_cells) return fail(ctx, C5_ERR_INVALID, "scalar count differs from the uploaded grid");
+    if (n_cells > 0 && (!alpha || !q)) return fail(ctx, C5_ERR_INVALID, "null scalar array");
+    int rc = bind_device(ctx);
+    if (rc) return rc;
+    C5_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_cells > 0) {
+        C5_HIP(ctx, hipMemcpy(ctx->alpha.ptr, alpha, static_cast<size_t>(n_cells) * 8, hipMemcpyHostToDevice));
+        C5_HIP(ctx, hipMemcpy(ctx->q.ptr, q, static_cast<size_t>(n_cells) * 8, hipMemcpyHostToDevice));
+    }
+    return C5_OK;
+}
+
+int c5_set_solid(c5_context* ctx, int slot, const double* tets, int64_t n_tets, double colour) {
+    if (!ctx) return fail(nullptr, C5_ERR_INVALID, "null context");
+    if (slot < 0 || slot >= C5_MAX_SOLIDS) return fail(ctx, C5_ERR_INVALID, "solid slot %d out of range", slot);
+    if (n_tets < 0 || (n_tets > 0 && !tets)) return fail(ctx, C5_ERR_INVALID, "bad solid array");
+    int rc = bind_device(ctx);
+    if (rc) return rc;
+    C5_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    Solid& s = ctx->solids[slot];
+    int64_t others = 0;
+    for (int k = 0; k < C5_MAX_SOLIDS; ++k)
+        if (k != slot) others += ctx->solids[k].n_tets;
+    if (others + n_tets >= static_cast<int64_t>(c5::kNoCell))
+        return fail(ctx, C5_ERR_INVALID, "solid cell count does not fit 28 bits");
+    s.n_tets = n_tets;
+    s.colour = colour;
+    if (n_tets > 0) {
+        const size_t bytes = static_cast<size_t>(n_tets) * 12 * sizeof(double);
+        C5_HIP(ctx, s.raw.ensure(bytes));
+        C5_HIP(ctx, s.view.ensure(bytes));
+        C5_HIP(ctx, hipMemcpy(s.raw.ptr, tets, bytes, hipMemcpyHostToDevice));
+    }
+    return C5_OK;
+}
+
+int c5_set_image(c5_context* ctx, int res_x, int res_y, const double* bounds4) {
+    if (!ctx) return fail(nullptr, C5_ERR_INVALID, "null context");
+    if (!bounds4) return fail(ctx, C5_ERR_INVALID, "plane initializer. wrong manual boundaries");  // plane.cpp:262-264
+    if (res_x < 2 || res_y < 2) return fail(ctx, C5_ERR_INVALID, "critical error. empty plane");
+    int rc = bind_device(ctx);
+    if (rc) return rc;
+    C5_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(ctx->bounds, bounds4, sizeof ctx->bounds);
+    c5::ImageParams& im = ctx->im;
+    im.res_x = res_x;
+    im.res_y = res_y;
+    im.x_min = bounds4[1];
+    im.y_min = bounds4[3];
+    // plane.cpp:295-302
+    im.step_x = (bounds4[0] - bounds4[1]) / (static_cast<double>(res_x) - 1.);
+    im.step_y = (bounds4[2] - bounds4[3]) / (static_cast<double>(res_y) - 1.);
+    // plane.cpp:304-314: coordinates are running sums
+    std::vector<double> X(static_cast<size_t>(res_x)), Y(static_cast<size_t>(res_y));
+    double cx = bounds4[1];
+    for (int i = 0; i < res_x; ++i) {
+        X[static_cast<size_t>(i)] = cx;
+        cx = cx + im.step_x;
+    }
+    double cy = bounds4[3];
+    for (int j = 0; j < res_y; ++j) {
+        Y[static_cast<size_t>(j)] = cy;
+        cy = cy + im.step_y;
+    }
+    C5_HIP(ctx, ctx->xtab.ensure(X.size() * 8));
+    C5_HIP(ctx, ctx->ytab.ensure(Y.size() * 8));
+    C5_HIP(ctx, hipMemcpy(ctx->xtab.ptr, X.data(), X.size() * 8, hipMemcpyHostToDevice));
+    C5_HIP(ctx, hipMemcpy(ctx->ytab.ptr, Y.data(), Y.size() * 8, hipMemcpyHostToDevice));
+    ctx->have_image = true;
+    recompute_rows(ctx);
+    return ensure_image_buffers(ctx);
+}
+
+int c5_set_row_tiles(c5_context* ctx, int tile_rows, int rank, int world) {
+    if (!ctx) return fail(nullptr, C5_ERR_INVALID, "null context");
+    if (world < 1 || rank < 0 || rank >= world) return fail(ctx, C5_ERR_INVALID, "bad rank/world %d/%d", rank, world);
+    if (tile_rows < 0) return fail(ctx, C5_ERR_INVALID, "bad tile_rows");
+    if (world > 1 && tile_rows == 0) return fail(ctx, C5_ERR_INVALID, "tile_rows must be > 0 when world > 1");
+    ctx->cfg_tile_rows = tile_rows;
+    ctx->cfg_rank = rank;
+    ctx->cfg_world = world;
+    if (ctx->have_image) {
+        int rc = bind_device(ctx);
+        if (rc) return rc;
+        C5_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        recompute_rows(ctx);
+        return ensure_image_buffers(ctx);
+    }
+    return C5_OK;
+}
+
+int c5_local_rows(const c5_context* ctx, int* n_rows) {
+    if (!ctx || !n_rows) return C5_ERR_INVALID;
+    *n_rows = ctx->have_image ? ctx->im.n_local_rows : 0;
+    return C5_OK;
+}
+
+int c5_set_view(c5_context* ctx, const c5_rotation* rots, int n_rots) {
+    if (!ctx) return fail(nullptr, C5_ERR_INVALID, "null context");
+    return to_rotation_list(ctx, rots, n_rots, ctx->view);
+}
+
+int c5_set_solid_view(c5_context* ctx, int slot, const c5_rotation* rots, int n_rots) {
+    if (!ctx) return fail(nullptr, C5_ERR_INVALID, "null context");
+    if (slot < 0 || slot >= C5_MAX_SOLIDS) return fail(ctx, C5_ERR_INVALID, "solid slot %d out of range", slot);
+    return to_rotation_list(ctx, rots, n_rots, ctx->solids[slot].rots);
+}
+
+int c5_set_alpha_limit(c5_context* ctx, double alpha_limit) {
+    if (!ctx) return fail(nullptr, C5_ERR_INVALID, "null context");
+    ctx->alpha_limit = alpha_limit;
+    return C5_OK;
+}
+
+int c5_set_option(c5_context* ctx, const char* name, double value) {
+    if (!ctx || !name) return fail(ctx, C5_ERR_INVALID, "null option");
+    const std::string n(name);
+    if (n == "tile") {
+        if (value < 0 || value > 2) return fail(ctx, C5_ERR_INVALID, "tile must be 0, 1 or 2");
+        ctx->tile_shape = static_cast<int>(value);
+    } else if (n == "transmittance_cutoff") {
+        ctx->t_cutoff = value;
+    } else if (n == "integration") {
+        ctx->order = static_cast<int>(value) != 0;
+    } else if (n == "xcd_mode") {
+        ctx->xcd_mode = static_cast<int>(value) != 0;
+    } else if (n == "stage_timing") {
+        ctx->stage_timing = static_cast<int>(value) != 0;
+    } else if (n == "walk_timing") {
+        ctx->walk_timing = static_cast<int>(value) != 0;
+    } else {
+        return fail(ctx, C5_ERR_INVALID, "unknown option '%s'", name);
+    }
+    return C5_OK;
+}
+
+int c5_render_device(c5_context* ctx, void* out_device) {
+    if (!ctx) return fail(nullptr, C5_ERR_INVALID, "null context");
+    if (!out_device) return fail(ctx, C5_ERR_INVALID, "null output pointer");
+    return enqueue_frame(ctx, static_cast<float2*>(out_device));
+}
+
+int c5_synchronize(c5_context* ctx) {
+    if (!ctx) return fail(nullptr, C5_ERR_INVALID, "null context");
+    int rc = bind_device(ctx);
+    if (rc) return rc;
+    C5_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return finish_frame(ctx);
+}
+
+int c5_render(c5_context* ctx, float* out_host) {
+    if (!ctx) return fail(nullptr, C5_ERR_INVALID, "null context");
+    if (!out_host) return fail(ctx, C5_ERR_INVALID, "null output pointer");
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        int rc = enqueue_frame(ctx, ctx->out.as<float2>());
+        if (rc) return rc;
+        rc = c5_synchronize(ctx);
+        if (rc == C5_RETRY) continue;
+        if (rc) return rc;
+        const size_t bytes = static_cast<size_t>(ctx->im.n_local_rows) * ctx->im.res_x * 2 * sizeof(float);
+        C5_HIP(ctx, hipMemcpy(out_host, ctx->out.ptr, bytes, hipMemcpyDeviceToHost));
+        return C5_OK;
+    }
+    return fail(ctx, C5_ERR_STATE, "entry buffer kept overflowing");
+}
+
+int c5_get_stats(c5_context* ctx, c5_stats* out) {
+    if (!ctx || !out) return fail(ctx, C5_ERR_INVALID, "null argument");
+    int rc = c5_synchronize(ctx);
+    *out = ctx->last;
+    return rc;
+}
+
+int c5_walk_kernel_ms(c5_context* ctx, int reset, double* avg_ms, int64_t* launches) {
+    if (!ctx) return fail(nullptr, C5_ERR_INVALID, "null context");
+    int rc = bind_device(ctx);
+    if (rc) return rc;
+    C5_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < ctx->walk_used; ++k) {
+        float ms = 0.f;
+        C5_HIP(ctx, hipEventElapsedTime(&ms, ctx->walk_a[k], ctx->walk_b[k]));
+        ctx->walk_ms_sum += ms;
+    }
+    ctx->walk_launches += ctx->walk_used;
+    ctx->walk_used = 0;
+    if (avg_ms) *avg_ms = ctx->walk_launches ? ctx->walk_ms_sum / static_cast<double>(ctx->walk_launches) : 0.0;
+    if (launches) *launches = ctx->walk_launches;
+    if (reset) {
+        ctx->walk_ms_sum = 0.0;
+        ctx->walk_launches = 0;
+    }
+    return C5_OK;
+}
+
+int c5_face_adjacency(const int32_t* cell_vert, int64_t n_cells, int64_t n_pts, int32_t* adj,
+                      int64_t* n_boundary_faces) {
+    if (n_cells < 0 || n_pts < 0 || (n_cells > 0 && (!cell_vert || !adj)))
+        return fail(nullptr, C5_ERR_INVALID, "bad adjacency arguments");
+    std::vector<int32_t> a;
+    std::vector<uint32_t> b;
+    std::string err;
+    if (!c5::build_face_adjacency(cell_vert, n_cells, n_pts, a, b, err))
+        return fail(nullptr, err.find("range") != std::string::npos ? C5_ERR_INVALID : C5_ERR_MESH, "%s", err.c_str());
+    if (n_cells > 0) std::memcpy(adj, a.data(), a.size() * sizeof(int32_t));
+    if (n_boundary_faces) *n_boundary_faces = static_cast<int64_t>(b.size());
+    return C5_OK;
+}
+
+int c5_download_view_points(c5_context* ctx, double* xyz) {
+    if (!ctx || !xyz) return fail(ctx, C5_ERR_INVALID, "null argument");
+    int rc = c5_synchronize(ctx);
+    if (rc && rc != C5_RETRY) return rc;
+    const size_t n = static_cast<size_t>(ctx->n_pts);
+    std::vector<double> x(n), y(n), z(n);
+    if (n) {
+        C5_HIP(ctx, hipMemcpy(x.data(), ctx->vx.ptr, n * 8, hipMemcpyDeviceToHost));
+        C5_HIP(ctx, hipMemcpy(y.data(), ctx->vy.ptr, n * 8, hipMemcpyDeviceToHost));
+        C5_HIP(ctx, hipMemcpy(z.data(), ctx->vz.ptr, n * 8, hipMemcpyDeviceToHost));
+    }
+    for (size_t i = 0; i < n; ++i) {
+        xyz[3 * i] = x[i];
+        xyz[3 * i + 1] = y[i];
+        xyz[3 * i + 2] = z[i];
+    }
+    return C5_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+// Device-side data layout of the MI355X render path (shared by host and kernels).
+//
+// Persistent grid (uploaded once, SoA, coalesced for the per-frame setup kernels):
+//   px/py/pz[n_pts]      fp64   raw vertex coordinates
+//   cell_vert[n_cells]   int4   cell -> vertex ids          (tetra.hpp:42 replaced by indices)
+//   cell_adj[n_cells]    int4   cell -> neighbour across face f (-1 = boundary)
+//   alpha/q[n_cells]     fp64   AbsorpCoef / radEnLooseRate (object3d_accretion_disk.cpp:4)
+//   bface[n_bfaces]      u32    (cell << 2 | face) of every face without a neighbour
+//
+// Per view (rebuilt every frame by build_records from the transformed vertices):
+//   CellRecord[n_cells]  128 B  one cache line: everything one walk step needs geometrically
+//   CellOptics[n_cells]   32 B  clamped absorption + source function
+//
+// Face numbering and vertex order follow the reference (plane.cpp:16-21,30-37; line.cpp:103-122):
+//   face 0 = (0,1,2), face 1 = (0,1,3), face 2 = (0,2,3), face 3 = (1,2,3).
+#pragma once
+
+#include <cstdint>
+
+namespace c5 {
+
+constexpr uint32_t kIdMask = 0x0FFFFFFFu;   // 28-bit cell id (line.hpp:71-79, line.cpp:27)
+constexpr uint32_t kNoCell = 0x0FFFFFFFu;   // neighbour field of a boundary face
+constexpr uint32_t kFaceUpper = 0x80000000u;  // cell body lies below the face plane (ray enters here when walking -z)
+constexpr uint32_t kFaceSkip = 0x40000000u;   // face is edge-on to the rays (no z(x,y)) or cell is flat
+
+// z of face k at pixel (x, y):  z = plane[k][0] + plane[k][1] * (x - x0) + plane[k][2] * (y - y0)
+// (line::find_polygon_intersection_z, line.cpp:150-174, rewritten about the cell-local origin
+// (x0, y0) = vertex 0 so the 128-byte record holds all four faces).
+struct alignas(16) CellRecord {
+    double x0, y0;
+    double plane[4][3];
+    uint32_t nbr[4];  // kIdMask bits: neighbour cell or kNoCell; kFaceUpper / kFaceSkip flags
+};
+static_assert(sizeof(CellRecord) == 128, "CellRecord must be one 128-byte line");
+
+// line.cpp:204-224 folded per cell: alpha_c = min(alpha, limit); cells with alpha_c < DBL_EPSILON
+// neither absorb nor emit (alpha_c = 0, source = 0); otherwise source = Q / alpha_c.
+struct alignas(16) CellOptics {
+    double alpha_raw;  // ch0 uses the unclamped value (line.cpp:189)
+    double alpha_c;
+    double source;
+    double q;
+};
+static_assert(sizeof(CellOptics) == 32, "CellOptics is 32 bytes");
+
+// A place where a ray enters the grid through a boundary face (walking from +z to -z).
+struct alignas(16) Entry {
+    double z;
+    int32_t cell;
+    int32_t pad;
+};
+
+constexpr int kMaxRotations = 8;
+struct RotationList {
+    int32_t n;
+    int32_t axis[kMaxRotations];
+    double cosv[kMaxRotations];
+    double sinv[kMaxRotations];
+    double x0[kMaxRotations];
+};
+
+struct ImageParams {
+    int32_t res_x, res_y;     // full image
+    int32_t n_local_rows;     // rows rendered by this context
+    int32_t tile_rows, rank, world;  // row tile t belongs to rank t % world
+    double x_min, y_min;      // bounds[1], bounds[3]
+    double step_x, step_y;    // plane.cpp:298-302
+};
+
+constexpr int kMaxSolids = 8;
+struct SolidTable {
+    int32_t n_slots;
+    uint32_t first_id[kMaxSolids + 1];  // mask value v (>0) belongs to slot s if first_id[s] < v <= first_id[s+1]
+    double colour[kMaxSolids];
+};
+
+struct FrameCounters {
+    unsigned long long segments;
+    unsigned long long steps;
+    unsigned long long covered;
+    unsigned long long solid_pixels;
+    unsigned long long entries;
+    unsigned int walk_overflow;
+    unsigned int entry_overflow;
+};
+
+// global row -> local row of this rank, or -1
+__host__ __device__ inline int local_row_of(const ImageParams& im, int row) {
+    const int tile = row / im.tile_rows;
+    if (tile % im.world != im.rank) return -1;
+    return (tile / im.world) * im.tile_rows + (row - tile * im.tile_rows);
+}
+// local row -> global row
+__host__ __device__ inline int global_row_of(const ImageParams& im, int lrow) {
+    const int ltile = lrow / im.tile_rows;
+    return (ltile * im.world + im.rank) * im.tile_rows + (lrow - ltile * im.tile_rows);
+}
+
+}  // namespace c5

@@ -1,0 +1,63 @@
+// Host-callable launchers of the gfx950 kernels (definitions in exact_kernels.hip and
+// walk_kernels.hip).  All launches are asynchronous on the given stream.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+#include "device_types.hpp"
+
+namespace c5 {
+
+struct GridView {  // device pointers of the persistent grid + per-view buffers
+    int64_t n_pts = 0, n_cells = 0, n_bfaces = 0;
+    const double *px = nullptr, *py = nullptr, *pz = nullptr;
+    double *vx = nullptr, *vy = nullptr, *vz = nullptr;
+    const int4* cell_vert = nullptr;
+    const int4* cell_adj = nullptr;
+    const double *alpha = nullptr, *q = nullptr;
+    const uint32_t* bface = nullptr;
+    CellRecord* rec = nullptr;
+    CellOptics* opt = nullptr;
+};
+
+struct WalkParams {
+    const CellRecord* rec;
+    const CellOptics* opt;
+    const int32_t* entry_offs;  // [n_local_px + 1]
+    const Entry* entries;
+    const uint32_t* mask;       // [n_local_px] or nullptr
+    SolidTable solids;
+    const double* Xtab;
+    const double* Ytab;
+    float2* out;                // [n_local_rows][res_x]
+    ImageParams im;
+    double t_cutoff;            // front-to-back early-out on transmittance
+    uint32_t max_steps;
+    int32_t xcd_mode;
+    int32_t order;              // 0: back to front in the reference's arithmetic; 1: front to back + early-out
+    FrameCounters* counters;
+};
+
+// exact_kernels.hip (-ffp-contract=off)
+void launch_transform_soa(hipStream_t s, const double* px, const double* py, const double* pz,
+                          double* vx, double* vy, double* vz, int64_t n, const RotationList& R);
+void launch_transform_aos(hipStream_t s, const double* in, double* out, int64_t n,
+                          const RotationList& R);
+void launch_solid_mask_raster(hipStream_t s, const double* tets, int64_t n_tets, uint32_t first_id,
+                              const double* Ytab, const ImageParams& im, uint32_t* mask);
+
+// walk_kernels.hip
+void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit);
+void launch_entry_count(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
+                        const ImageParams& im, int32_t* count, int want_upper);
+void launch_entry_fill(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
+                       const ImageParams& im, int32_t* count, const int32_t* offs, Entry* entries,
+                       int64_t capacity, FrameCounters* counters, int want_upper);
+// exclusive scan of count[n] into offs[n + 1]; scratch holds >= (n / 1024 + 2) int32
+void launch_exclusive_scan(hipStream_t s, const int32_t* count, int32_t* offs, int64_t n,
+                           int32_t* scratch, FrameCounters* counters);
+void launch_walk(hipStream_t s, const WalkParams& p, int tile_shape);
+
+}  // namespace c5

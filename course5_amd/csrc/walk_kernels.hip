@@ -1,0 +1,536 @@
+// gfx950 kernels of the render hot path (fp64; FMA contraction allowed here).
+//
+//   build_records    per view: cell -> 128-byte walk record (four face planes about a cell-local
+//                    origin, neighbour ids, orientation flags) + 32-byte optics record.
+//                    Replaces the per-segment plane solve line::find_polygon_intersection_z
+//                    (line.cpp:150-174) and the per-step clamp/divide of
+//                    line::integrate_ray_value_by_i (line.cpp:213-224).
+//   entry_raster     boundary faces facing the viewer -> per-pixel entry records (CSR).
+//                    Replaces the part of plane::find_intersections (plane.cpp:184-192) that
+//                    discovers where a ray meets the grid; re-entries of non-convex grids
+//                    are further entries of the same pixel.
+//   walk_composite   one lane per pixel: face-adjacency walk along z; tau and the
+//                    emission/absorption integral, either back to front in the reference's own
+//                    arithmetic (default) or front to back with a transmittance early-out.
+//                    Replaces plane::trace_rays' loop body (plane.cpp:161-169):
+//                    line::calculate_intersections + std::sort (line.cpp:84-148),
+//                    direct_calculate_ray_value (line.cpp:176-193) and
+//                    integrate_ray_value_by_i (line.cpp:195-227), fp32 store (plane.cpp:165-166).
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+#include "device_types.hpp"
+#include "kernels.hpp"
+
+namespace c5 {
+
+// ------------------------------------------------------------------------------------------
+// build_records
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void build_records(GridView g, double alpha_limit) {
+    const int64_t cell = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (cell >= g.n_cells) return;
+    const int4 cv = g.cell_vert[cell];
+    const int4 adj = g.cell_adj[cell];
+    const int vid[4] = {cv.x, cv.y, cv.z, cv.w};
+    const int nb[4] = {adj.x, adj.y, adj.z, adj.w};
+    double p[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        p[k][0] = g.vx[vid[k]];
+        p[k][1] = g.vy[vid[k]];
+        p[k][2] = g.vz[vid[k]];
+    }
+    CellRecord r;
+    r.x0 = p[0][0];
+    r.y0 = p[0][1];
+    // faces in the reference's numbering and vertex order (plane.cpp:30-37, line.cpp:103-122)
+    constexpr int FV[4][4] = {{0, 1, 2, 3}, {0, 1, 3, 2}, {0, 2, 3, 1}, {1, 2, 3, 0}};
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const double* a = p[FV[f][0]];
+        const double* b = p[FV[f][1]];
+        const double* c = p[FV[f][2]];
+        const double* o = p[FV[f][3]];
+        // line.cpp:158-171: z = ((y-ay)*A - (x-ax)*B)/m + az
+        const double A = (b[0] - a[0]) * (c[2] - a[2]) - (c[0] - a[0]) * (b[2] - a[2]);
+        const double B = (b[1] - a[1]) * (c[2] - a[2]) - (c[1] - a[1]) * (b[2] - a[2]);
+        const double m = (b[0] - a[0]) * (c[1] - a[1]) - (c[0] - a[0]) * (b[1] - a[1]);
+        const double gy = A / m;
+        const double gx = -B / m;
+        const double c0 = a[2] + gx * (r.x0 - a[0]) + gy * (r.y0 - a[1]);
+        const double z_under_opp = c0 + gx * (o[0] - r.x0) + gy * (o[1] - r.y0);
+        uint32_t w = (nb[f] < 0) ? kNoCell : (static_cast<uint32_t>(nb[f]) & kIdMask);
+        const bool finite = (fabs(gx) <= DBL_MAX) && (fabs(gy) <= DBL_MAX) && (fabs(c0) <= DBL_MAX);
+        if (!finite || !(o[2] != z_under_opp)) {
+            w |= kFaceSkip;
+        } else if (o[2] < z_under_opp) {
+            w |= kFaceUpper;
+        }
+        r.plane[f][0] = finite ? c0 : 0.0;
+        r.plane[f][1] = finite ? gx : 0.0;
+        r.plane[f][2] = finite ? gy : 0.0;
+        r.nbr[f] = w;
+    }
+    g.rec[cell] = r;
+
+    // line.cpp:204-224
+    const double a_raw = g.alpha[cell];
+    const double qv = g.q[cell];
+    double a_c = a_raw;
+    if (a_c > alpha_limit) a_c = alpha_limit;
+    CellOptics o;
+    o.alpha_raw = a_raw;
+    o.q = qv;
+    if (a_c < DBL_EPSILON) {
+        o.alpha_c = 0.0;
+        o.source = 0.0;
+    } else {
+        o.alpha_c = a_c;
+        o.source = qv / a_c;
+    }
+    g.opt[cell] = o;
+}
+
+void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit) {
+    if (g.n_cells <= 0) return;
+    const unsigned blocks = static_cast<unsigned>((g.n_cells + 255) / 256);
+    hipLaunchKernelGGL(build_records, dim3(blocks), dim3(256), 0, s, g, alpha_limit);
+}
+
+// ------------------------------------------------------------------------------------------
+// entry_raster: one wavefront per boundary face
+// ------------------------------------------------------------------------------------------
+template <int PASS>
+__global__ __launch_bounds__(256) void entry_raster(GridView g, const double* __restrict__ Xtab,
+                                                    const double* __restrict__ Ytab, ImageParams im,
+                                                    int32_t* __restrict__ count,
+                                                    const int32_t* __restrict__ offs,
+                                                    Entry* __restrict__ entries, int64_t capacity,
+                                                    FrameCounters* counters, int want_upper) {
+    const int lane = threadIdx.x & 63;
+    const int64_t face_idx = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (face_idx >= g.n_bfaces) return;
+    const uint32_t bf = g.bface[face_idx];
+    const uint32_t cell = bf >> 2;
+    const int f = static_cast<int>(bf & 3u);
+    const CellRecord* rec = g.rec + cell;
+    const uint32_t w = rec->nbr[f];
+    // walking from +z to -z a ray enters through faces the cell body lies below (upper faces);
+    // walking from -z to +z through the others
+    if ((w & kFaceSkip) || (((w & kFaceUpper) != 0) != (want_upper != 0))) return;
+
+    const int4 cv = g.cell_vert[cell];
+    const int vid[4] = {cv.x, cv.y, cv.z, cv.w};
+    const int i0 = (f == 3) ? 1 : 0;
+    const int i1 = (f <= 1) ? 1 : 2;
+    const int i2 = (f == 0) ? 2 : 3;
+    const double ax = g.vx[vid[i0]], ay = g.vy[vid[i0]];
+    const double bx = g.vx[vid[i1]], by = g.vy[vid[i1]];
+    const double cx = g.vx[vid[i2]], cy = g.vy[vid[i2]];
+
+    const double xmin = fmin(ax, fmin(bx, cx)), xmax = fmax(ax, fmax(bx, cx));
+    const double ymin = fmin(ay, fmin(by, cy)), ymax = fmax(ay, fmax(by, cy));
+    // conservative pixel box (the tables are accumulated sums, so widen by one)
+    double fc0 = floor((xmin - im.x_min) / im.step_x) - 1.0;
+    double fc1 = ceil((xmax - im.x_min) / im.step_x) + 1.0;
+    double fr0 = floor((ymin - im.y_min) / im.step_y) - 1.0;
+    double fr1 = ceil((ymax - im.y_min) / im.step_y) + 1.0;
+    if (!(fc1 >= 0.0) || !(fr1 >= 0.0) || !(fc0 <= im.res_x - 1.0) || !(fr0 <= im.res_y - 1.0)) return;
+    const int c0 = static_cast<int>(fmax(fc0, 0.0));
+    const int c1 = static_cast<int>(fmin(fc1, im.res_x - 1.0));
+    const int r0 = static_cast<int>(fmax(fr0, 0.0));
+    const int r1 = static_cast<int>(fmin(fr1, im.res_y - 1.0));
+    const int bw = c1 - c0 + 1;
+    const int64_t n_box = static_cast<int64_t>(bw) * (r1 - r0 + 1);
+
+    const double x0 = rec->x0, y0 = rec->y0;
+    const double pc = rec->plane[f][0], pgx = rec->plane[f][1], pgy = rec->plane[f][2];
+
+    for (int64_t idx = lane; idx < n_box; idx += 64) {
+        const int row = r0 + static_cast<int>(idx / bw);
+        const int col = c0 + static_cast<int>(idx % bw);
+        const int lrow = local_row_of(im, row);
+        if (lrow < 0) continue;
+        const double x = Xtab[col], y = Ytab[row];
+        // closed point-in-triangle test, either winding
+        const double e0 = (bx - ax) * (y - ay) - (by - ay) * (x - ax);
+        const double e1 = (cx - bx) * (y - by) - (cy - by) * (x - bx);
+        const double e2 = (ax - cx) * (y - cy) - (ay - cy) * (x - cx);
+        const bool in = (e0 >= 0 && e1 >= 0 && e2 >= 0) || (e0 <= 0 && e1 <= 0 && e2 <= 0);
+        if (!in) continue;
+        const size_t lp = static_cast<size_t>(lrow) * im.res_x + col;
+        if (PASS == 0) {
+            atomicAdd(count + lp, 1);
+        } else {
+            const int k = atomicSub(count + lp, 1) - 1;
+            const int64_t slot = static_cast<int64_t>(offs[lp]) + k;
+            if (slot < capacity) {
+                Entry e;
+                e.z = pc + pgx * (x - x0) + pgy * (y - y0);
+                e.cell = static_cast<int32_t>(cell);
+                e.pad = 0;
+                entries[slot] = e;
+            } else {
+                atomicOr(&counters->entry_overflow, 1u);
+            }
+        }
+    }
+}
+
+void launch_entry_count(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
+                        const ImageParams& im, int32_t* count, int want_upper) {
+    if (g.n_bfaces <= 0) return;
+    const unsigned blocks = static_cast<unsigned>((g.n_bfaces + 3) / 4);
+    hipLaunchKernelGGL(entry_raster<0>, dim3(blocks), dim3(256), 0, s, g, Xtab, Ytab, im, count,
+                       static_cast<const int32_t*>(nullptr), static_cast<Entry*>(nullptr),
+                       static_cast<int64_t>(0), static_cast<FrameCounters*>(nullptr), want_upper);
+}
+
+void launch_entry_fill(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
+                       const ImageParams& im, int32_t* count, const int32_t* offs, Entry* entries,
+                       int64_t capacity, FrameCounters* counters, int want_upper) {
+    if (g.n_bfaces <= 0) return;
+    const unsigned blocks = static_cast<unsigned>((g.n_bfaces + 3) / 4);
+    hipLaunchKernelGGL(entry_raster<1>, dim3(blocks), dim3(256), 0, s, g, Xtab, Ytab, im, count, offs,
+                       entries, capacity, counters, want_upper);
+}
+
+// ------------------------------------------------------------------------------------------
+// exclusive scan (int32), 1024 items per block
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// returns the exclusive prefix of `v` over the 256 threads of the block, total in *block_total
+__device__ __forceinline__ int block_exclusive_scan(int v, int* block_total) {
+    __shared__ int wave_sums[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int inc = wave_inclusive_scan(v, lane);
+    if (lane == 63) wave_sums[wave] = inc;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < wave) base += wave_sums[k];
+        total += wave_sums[k];
+    }
+    __syncthreads();
+    *block_total = total;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void scan_block_sums(const int32_t* __restrict__ count, int64_t n,
+                                                       int32_t* __restrict__ sums) {
+    const int64_t base = (blockIdx.x * 256ll + threadIdx.x) * 4;
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (base + k < n) v += count[base + k];
+    int total;
+    block_exclusive_scan(v, &total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void scan_sums_inplace(int32_t* __restrict__ sums, int64_t n_blocks) {
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t start = 0; start < n_blocks; start += 256) {
+        const int64_t i = start + threadIdx.x;
+        const int v = (i < n_blocks) ? sums[i] : 0;
+        int total;
+        const int ex = block_exclusive_scan(v, &total);
+        const int carry = carry_s;
+        if (i < n_blocks) sums[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[n_blocks] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void scan_finish(const int32_t* __restrict__ count, int64_t n,
+                                                   const int32_t* __restrict__ sums,
+                                                   int32_t* __restrict__ offs, int64_t n_blocks,
+                                                   FrameCounters* counters) {
+    const int64_t base = (blockIdx.x * 256ll + threadIdx.x) * 4;
+    int c[4];
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        c[k] = (base + k < n) ? count[base + k] : 0;
+        v += c[k];
+    }
+    int total;
+    int run = block_exclusive_scan(v, &total) + sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < n) offs[base + k] = run;
+        run += c[k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int grand = sums[n_blocks];
+        offs[n] = grand;
+        if (counters) counters->entries = static_cast<unsigned long long>(grand);
+    }
+}
+
+void launch_exclusive_scan(hipStream_t s, const int32_t* count, int32_t* offs, int64_t n,
+                           int32_t* scratch, FrameCounters* counters) {
+    if (n <= 0) return;
+    const int64_t n_blocks = (n + 1023) / 1024;
+    hipLaunchKernelGGL(scan_block_sums, dim3(static_cast<unsigned>(n_blocks)), dim3(256), 0, s, count, n, scratch);
+    hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(256), 0, s, scratch, n_blocks);
+    hipLaunchKernelGGL(scan_finish, dim3(static_cast<unsigned>(n_blocks)), dim3(256), 0, s, count, n, scratch,
+                       offs, n_blocks, counters);
+}
+
+// ------------------------------------------------------------------------------------------
+// walk_composite
+// ------------------------------------------------------------------------------------------
+template <int TILE>
+struct TileShape;
+template <>
+struct TileShape<0> {  // each wavefront owns a 64x1 row tile; workgroup 64 x 4
+    static constexpr int WW = 64, WH = 1, GX = 1, GY = 4;
+};
+template <>
+struct TileShape<1> {  // 16x4 per wavefront; workgroup 32 x 8
+    static constexpr int WW = 16, WH = 4, GX = 2, GY = 2;
+};
+template <>
+struct TileShape<2> {  // 8x8 per wavefront; workgroup 16 x 16
+    static constexpr int WW = 8, WH = 8, GX = 2, GY = 2;
+};
+
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+struct alignas(16) D2 {
+    double a, b;
+};
+
+// One emission/absorption step in the reference's own arithmetic (line.cpp:220-224):
+//   C = Q - alpha * I;   I = (Q - C * exp(-alpha * dz)) / alpha
+// with every product and sum rounded separately (no FMA contraction), so that the recurrence —
+// including its cancellation noise for tiny alpha — follows the reference's to the last bits of exp.
+__device__ __forceinline__ double reference_emission_step(double I, double alpha_c, double q, double dz) {
+#pragma clang fp contract(off)
+    const double C = q - alpha_c * I;
+    const double arg = -alpha_c * dz;
+    const double e = exp(arg);
+    return (q - C * e) / alpha_c;
+}
+
+// ORDER 0: walk from -z to +z and integrate back to front exactly like
+//          line::integrate_ray_value_by_i (the reference sorts by z_hi descending and runs the
+//          recurrence from the last element, line.cpp:138,206).  Default: parity first.
+// ORDER 1: walk from +z (the viewer) to -z, I = sum_k T_k S_k with the transmittance early-out
+//          (wavefront-uniform skip of the exp work once every lane's T fell below the cut-off).
+//          Algebraically identical; differs from ORDER 0 by rounding only where the reference's
+//          recurrence is itself well conditioned.
+template <int TILE, int ORDER>
+__global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
+    using TS = TileShape<TILE>;
+    constexpr int TW = TS::WW * TS::GX, TH = TS::WH * TS::GY;
+    constexpr bool kUp = (ORDER == 0);  // walking towards +z
+    const ImageParams& im = P.im;
+    const int tiles_x = (im.res_x + TW - 1) / TW;
+    const int tiles_y = (im.n_local_rows + TH - 1) / TH;
+
+    int tx, ty;
+    if (P.xcd_mode == 0) {
+        ty = blockIdx.x / tiles_x;
+        tx = blockIdx.x - ty * tiles_x;
+    } else {
+        // Bands of ~32 image rows are dealt round-robin to the 8 XCDs (blocks b and b + 8 share an
+        // XCD's L2): every XCD sweeps the image top to bottom, so load stays balanced, while the
+        // workgroups resident on one XCD at a time cover a compact region of the grid.
+        constexpr int BAND = (32 / TH) > 0 ? (32 / TH) : 1;
+        const int n_bands = (tiles_y + BAND - 1) / BAND;
+        const int per_band = BAND * tiles_x;
+        const int xcd = blockIdx.x & 7;
+        const int seq = blockIdx.x >> 3;
+        const int band = (seq / per_band) * 8 + xcd;
+        const int within = seq - (seq / per_band) * per_band;
+        if (band >= n_bands) return;
+        ty = band * BAND + within % BAND;
+        tx = within / BAND;
+        if (ty >= tiles_y) return;
+    }
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = tx * TW + (wave % TS::GX) * TS::WW + (lane % TS::WW);
+    const int lrow = ty * TH + (wave / TS::GX) * TS::WH + (lane / TS::WW);
+    const bool in_image = (col < im.res_x) && (lrow < im.n_local_rows);
+
+    unsigned n_seg = 0, n_step = 0, is_solid = 0, overflow = 0;
+    double tau = 0.0, I = 0.0;
+    float2 result = make_float2(0.f, 0.f);
+    size_t lp = 0;
+
+    if (in_image) {
+        lp = static_cast<size_t>(lrow) * im.res_x + col;
+        const uint32_t mv = P.mask ? P.mask[lp] : 0u;
+        if (mv) {
+            // line.cpp:177-179,197-199: a solid-marked pixel returns the mark on both channels
+            double colour = 0.0;
+            for (int s = 0; s < P.solids.n_slots; ++s)
+                if (mv > P.solids.first_id[s] && mv <= P.solids.first_id[s + 1]) colour = P.solids.colour[s];
+            result.x = static_cast<float>(colour);
+            result.y = result.x;
+            is_solid = 1;
+        } else {
+            const double x = P.Xtab[col];
+            const double y = P.Ytab[global_row_of(im, lrow)];
+            const int e0 = P.entry_offs[lp], e1 = P.entry_offs[lp + 1];
+            double T = 1.0;
+            // position along the ray, measured so that it always decreases: s = z walking down, -z walking up
+            double s_cur = DBL_MAX;
+            bool stop = (e1 <= e0);
+            while (!stop) {
+                // next place the ray enters the grid beyond s_cur
+                double s_best = -DBL_MAX;
+                int cell = -1;
+                for (int e = e0; e < e1; ++e) {
+                    const Entry en = P.entries[e];
+                    const double se = kUp ? -en.z : en.z;
+                    if (se < s_cur && se > s_best) {
+                        s_best = se;
+                        cell = en.cell;
+                    }
+                }
+                if (cell < 0) break;
+                s_cur = s_best;
+                while (true) {
+                    const D2* rp = reinterpret_cast<const D2*>(P.rec + cell);
+                    const D2* op = reinterpret_cast<const D2*>(P.opt + cell);
+                    const D2 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4], r5 = rp[5],
+                             r6 = rp[6], r7 = rp[7];
+                    const D2 o0 = op[0], o1 = op[1];
+                    const double dx = x - r0.a, dy = y - r0.b;
+                    // plane k = (c, gx, gy): r1.a r1.b r2.a | r2.b r3.a r3.b | r4.a r4.b r5.a | r5.b r6.a r6.b
+                    const double z0 = fma(r1.b, dx, fma(r2.a, dy, r1.a));
+                    const double z1 = fma(r3.a, dx, fma(r3.b, dy, r2.b));
+                    const double z2 = fma(r4.b, dx, fma(r5.a, dy, r4.a));
+                    const double z3 = fma(r6.a, dx, fma(r6.b, dy, r5.b));
+                    const unsigned long long w01 = __double_as_longlong(r7.a);
+                    const unsigned long long w23 = __double_as_longlong(r7.b);
+                    const uint32_t w0 = static_cast<uint32_t>(w01), w1 = static_cast<uint32_t>(w01 >> 32);
+                    const uint32_t w2 = static_cast<uint32_t>(w23), w3 = static_cast<uint32_t>(w23 >> 32);
+
+                    // the ray is inside the cell between the highest lower face and the lowest upper face
+                    double z_top = DBL_MAX, z_bot = -DBL_MAX;
+                    uint32_t w_top = kNoCell | kFaceSkip, w_bot = kNoCell | kFaceSkip;  // "no such face"
+#define C5_FACE(zk, wk)                                   \
+    if (!((wk)&kFaceSkip)) {                              \
+        if ((wk)&kFaceUpper) {                            \
+            if ((zk) < z_top) {                           \
+                z_top = (zk);                             \
+                w_top = (wk);                             \
+            }                                             \
+        } else if ((zk) > z_bot) {                        \
+            z_bot = (zk);                                 \
+            w_bot = (wk);                                 \
+        }                                                 \
+    }
+                    C5_FACE(z0, w0)
+                    C5_FACE(z1, w1)
+                    C5_FACE(z2, w2)
+                    C5_FACE(z3, w3)
+#undef C5_FACE
+                    const double dz = z_top - z_bot;  // line.cpp:124-131
+                    ++n_step;
+                    if (dz > 0.0 && z_top < DBL_MAX && z_bot > -DBL_MAX) {
+                        ++n_seg;
+                        tau = fma(dz, o0.a, tau);  // line.cpp:189 (unclamped alpha)
+                        if (ORDER == 0) {
+                            if (o0.b != 0.0) I = reference_emission_step(I, o0.b, o1.b, dz);  // line.cpp:220-224 (NaN alpha propagates)
+                        } else if (T >= P.t_cutoff) {
+                            // I = sum_k T_k (Q/alpha)(1 - e^{-alpha dz}); T_{k+1} = T_k e^{-alpha dz}
+                            const double ex = exp(-o0.b * dz);
+                            I = fma(T * o1.a, 1.0 - ex, I);
+                            T *= ex;
+                        }
+                    }
+                    const uint32_t w_out = kUp ? w_top : w_bot;
+                    if (w_out & kFaceSkip) break;  // no exit face: flat cell, give up on this span
+                    s_cur = fmin(s_cur, kUp ? -z_top : z_bot);
+                    const uint32_t nb = w_out & kIdMask;
+                    if (nb == kNoCell) break;  // left the grid; look for a re-entry
+                    cell = static_cast<int>(nb);
+                    if (n_step >= P.max_steps) {
+                        overflow = 1;
+                        stop = true;
+                        break;
+                    }
+                }
+            }
+            result.x = static_cast<float>(tau);  // plane.cpp:165
+            result.y = static_cast<float>(I);    // plane.cpp:166
+        }
+        P.out[lp] = result;
+    }
+
+    // per-wavefront statistics -> one atomic each
+    const unsigned s_seg = wave_sum_u32(n_seg);
+    const unsigned s_step = wave_sum_u32(n_step);
+    const unsigned s_cov = wave_sum_u32(n_seg > 0 ? 1u : 0u);
+    const unsigned s_sol = wave_sum_u32(is_solid);
+    const unsigned s_ovf = wave_sum_u32(overflow);
+    if (lane == 0) {
+        if (s_seg) atomicAdd(&P.counters->segments, static_cast<unsigned long long>(s_seg));
+        if (s_step) atomicAdd(&P.counters->steps, static_cast<unsigned long long>(s_step));
+        if (s_cov) atomicAdd(&P.counters->covered, static_cast<unsigned long long>(s_cov));
+        if (s_sol) atomicAdd(&P.counters->solid_pixels, static_cast<unsigned long long>(s_sol));
+        if (s_ovf) atomicAdd(&P.counters->walk_overflow, s_ovf);
+    }
+}
+
+template <int TILE, int ORDER>
+static void launch_walk_t(hipStream_t s, const WalkParams& p) {
+    using TS = TileShape<TILE>;
+    constexpr int TW = TS::WW * TS::GX, TH = TS::WH * TS::GY;
+    const int tiles_x = (p.im.res_x + TW - 1) / TW;
+    const int tiles_y = (p.im.n_local_rows + TH - 1) / TH;
+    if (tiles_x <= 0 || tiles_y <= 0) return;
+    long long blocks;
+    if (p.xcd_mode == 0) {
+        blocks = static_cast<long long>(tiles_x) * tiles_y;
+    } else {
+        constexpr int BAND = (32 / TH) > 0 ? (32 / TH) : 1;
+        const int n_bands = (tiles_y + BAND - 1) / BAND;
+        const int rounds = (n_bands + 7) / 8;
+        blocks = 8ll * rounds * BAND * tiles_x;
+    }
+    hipLaunchKernelGGL((walk_composite<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+}
+
+void launch_walk(hipStream_t s, const WalkParams& p, int tile_shape) {
+    if (p.order == 0) {
+        switch (tile_shape) {
+            case 1: launch_walk_t<1, 0>(s, p); break;
+            case 2: launch_walk_t<2, 0>(s, p); break;
+            default: launch_walk_t<0, 0>(s, p); break;
+        }
+    } else {
+        switch (tile_shape) {
+            case 1: launch_walk_t<1, 1>(s, p); break;
+            case 2: launch_walk_t<2, 1>(s, p); break;
+            default: launch_walk_t<0, 1>(s, p); break;
+        }
+    }
+}
+
+}  // namespace c5

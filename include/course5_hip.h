@@ -1,0 +1,164 @@
+/*
+ * course5_hip.h — C ABI of the MI355X (gfx950) render path for mlozhechko/course5.
+ *
+ * The reference has no FFI: its seam is three C++ calls made once per frame from
+ * project/src/main.cpp:127-129,
+ *
+ *     plane base_plane{res_x, res_y, {acc_disk, roche_lobe, acc_sphere}, domain};   // plane.cpp:260-315
+ *     base_plane.find_intersections();                                              // plane.cpp:184-192
+ *     object2d result = base_plane.trace_rays(tetra_value::alpha, tetra_value::Q);  // plane.cpp:144-172
+ *
+ * preceded by the view transform object3d_base::rotate_around_{x,y}_axis
+ * (object3d_base.cpp:202-219, main.cpp:105-107,112-114).  This header is what a maintainer
+ * binds in their place (INTEGRATION.md shows the edit).  Everything is extern "C" with plain
+ * pointers and sizes; no C++ types, no exceptions and no torch types cross it.
+ *
+ * Conventions
+ *   - every function returns an int status (C5_OK == 0); c5_last_error() gives the message
+ *     (the reference throws std::runtime_error instead: plane.cpp:40,152,263,270, line.cpp:45);
+ *   - a context is used by one host thread at a time and drives one GPU;
+ *   - caller keeps ownership of every host array; the library copies what it needs;
+ *   - image layout is out[row][col][2] fp32, col fastest, channel innermost — the order
+ *     object2d::export_to_vti writes (object2d.cpp:17-21); channel 0 = tau
+ *     (line.cpp:176-193), channel 1 = I (line.cpp:195-227).
+ */
+#ifndef COURSE5_HIP_H
+#define COURSE5_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C5_ABI_VERSION 1
+
+enum {
+    C5_OK = 0,
+    C5_ERR_INVALID = 1,     /* bad argument (null pointer, size, id range) */
+    C5_ERR_STATE = 2,       /* call order: render before grid/image were set */
+    C5_ERR_HIP = 3,         /* HIP runtime failure (message carries hipGetErrorString) */
+    C5_ERR_MESH = 4,        /* non-conforming grid: a face shared by more than two cells */
+    C5_ERR_NO_DEVICE = 5,   /* no usable GPU */
+    C5_ERR_WALK = 6,        /* a ray exceeded the step bound (malformed grid) */
+    C5_RETRY = 7            /* c5_synchronize: an internal buffer was too small and has been
+                               grown; the frame is incomplete, call c5_render_device again */
+};
+
+#define C5_MAX_ROTATIONS 8
+#define C5_MAX_SOLIDS 8
+
+typedef struct c5_context c5_context;
+
+/* One elementary in-place rotation, applied in list order to every vertex.
+ * axis 0: tetra::point_rotate_around_x_axis (tetra.cpp:44-48);
+ * axis 1: tetra::point_rotate_around_y_axis about the line x = x0, z = 0 (tetra.cpp:51-62).
+ * The host evaluates cos/sin (libm, like the reference); the device applies them with
+ * separately rounded multiplies and adds, so transformed vertices equal the reference's. */
+typedef struct c5_rotation {
+    int32_t axis;
+    int32_t reserved;
+    double angle; /* radians */
+    double x0;
+} c5_rotation;
+
+typedef struct c5_stats {
+    int64_t segments;        /* ray-tet segments with dz > 0 == plane::count_all_intersections (plane.cpp:3-12) */
+    int64_t covered_pixels;  /* pixels with at least one segment */
+    int64_t solid_pixels;    /* pixels overwritten by a solid colour (line.cpp:246-249) */
+    int64_t entries;         /* boundary entry records produced by the entry raster */
+    int64_t boundary_faces;  /* static: faces with no neighbour */
+    int64_t steps;           /* walk steps taken (>= segments) */
+    int32_t walk_overflow;   /* rays that hit the step bound */
+    int32_t entry_overflow;  /* entry buffer had to grow (frame was re-rendered) */
+    /* GPU time of the last frame per stage, milliseconds (HIP events on the context stream) */
+    float ms_transform;      /* view transform                     (a2) */
+    float ms_records;        /* per-cell walk records              (a1, a10) */
+    float ms_entries;        /* boundary entry raster + scan       (a6/a7 for boundary faces) */
+    float ms_solids;         /* solid mask raster                  (a6, a9) */
+    float ms_walk;           /* walk_composite                     (a11-a14) */
+    float ms_total;          /* first kernel start -> image complete in HBM */
+} c5_stats;
+
+/* --- lifetime ----------------------------------------------------------------------------- */
+int c5_abi_version(void);
+int c5_device_count(int* count);
+int c5_create(int device_ordinal, c5_context** out_ctx);
+void c5_destroy(c5_context* ctx);
+/* Message of the last failure on ctx (or of the last c5_create failure when ctx == NULL). */
+const char* c5_last_error(const c5_context* ctx);
+
+/* Run the context's work on a caller-owned HIP stream (hipStream_t passed as void*), e.g. the
+ * stream of the framework that owns the output buffer, so that ordering with the caller's own
+ * kernels and collectives needs no host synchronisation.  NULL restores the context's own stream. */
+int c5_set_stream(c5_context* ctx, void* hip_stream);
+
+/* --- scene (persistent across frames) ------------------------------------------------------ */
+/* Volume grid: replaces object3d_base::read_vtk_file's per-cell copies (object3d_base.cpp:13-53)
+ * and the tetra AoS (tetra.hpp:12-46).  xyz[n_pts][3] raw (untransformed) points,
+ * cell_vert[n_cells][4] point ids, alpha/q[n_cells] = AbsorpCoef / radEnLooseRate
+ * (object3d_accretion_disk.cpp:4).  Builds face adjacency; n_cells must be < 2^28
+ * (line.hpp:71-79). */
+int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int32_t* cell_vert,
+                   int64_t n_cells, const double* alpha, const double* q);
+/* Replace only the cell scalars of the uploaded grid. */
+int c5_update_scalars(c5_context* ctx, const double* alpha, const double* q, int64_t n_cells);
+/* Solid object `slot` (0..C5_MAX_SOLIDS-1): tets[n][4][3] raw vertex copies, one colour.
+ * Replaces the solid part of the tetra vector (main.cpp:110-116,127; plane.cpp:130-131).
+ * n == 0 removes the object.  Higher slots / higher tet index win ties, like serial -j1. */
+int c5_set_solid(c5_context* ctx, int slot, const double* tets, int64_t n_tets, double colour);
+
+/* --- per-frame parameters -------------------------------------------------------------------- */
+/* plane::plane(res_x, res_y, ..., bounds) (plane.cpp:260-315); bounds4 in the reference's order
+ * {x_max, x_min, y_max, y_min} (main.cpp:83). */
+int c5_set_image(c5_context* ctx, int res_x, int res_y, const double* bounds4);
+/* Row sharding for multi-GPU: rows are grouped in tiles of tile_rows; tile t belongs to
+ * rank t % world.  Default (1 tile of res_y rows, world 1) renders the whole image.  The local
+ * strip holds this rank's rows in ascending global order. */
+int c5_set_row_tiles(c5_context* ctx, int tile_rows, int rank, int world);
+int c5_local_rows(const c5_context* ctx, int* n_rows);
+/* View transform of the volume grid (main.cpp:105-107) and of each solid (main.cpp:112-114,
+ * object3d_roche_lobe.cpp:48). */
+int c5_set_view(c5_context* ctx, const c5_rotation* rots, int n_rots);
+int c5_set_solid_view(c5_context* ctx, int slot, const c5_rotation* rots, int n_rots);
+/* app::config.limit_alpha_value (config.hpp:25, line.cpp:204,216-218); default 2.5. */
+int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
+/* Knobs:
+ *   "integration"  0 (default): rays are walked from -z to +z and ch1 is integrated back to front
+ *                  with the reference's own recurrence and rounding (line.cpp:206-225);
+ *                  1: front to back from the viewer, I = sum T_k S_k, with the wavefront early-out
+ *                  once the transmittance T falls below "transmittance_cutoff" (default 1e-12,
+ *                  0 disables).  Both agree to rounding wherever the reference's recurrence is
+ *                  well conditioned (it is not for DBL_EPSILON <= alpha < ~1e-8).
+ *   "tile"         wavefront tile: 0 = 64x1 row tile, 1 = 16x4, 2 = 8x8 pixels.
+ *   "xcd_mode"     1 (default): 32-row bands dealt round-robin to the 8 XCDs; 0: row-major tiles.
+ *   "stage_timing" / "walk_timing"  0/1: record HIP events per stage / around walk_composite. */
+int c5_set_option(c5_context* ctx, const char* name, double value);
+
+/* --- render ---------------------------------------------------------------------------------- */
+/* find_intersections + trace_rays for the local rows.  out_host[local_rows][res_x][2]. */
+int c5_render(c5_context* ctx, float* out_host);
+/* Same, asynchronous on the context's stream, into device memory (hipMalloc'ed by anyone in
+ * this process).  Pair with c5_synchronize. */
+int c5_render_device(c5_context* ctx, void* out_device);
+int c5_synchronize(c5_context* ctx);
+/* Statistics of the last completed frame (synchronizes). */
+int c5_get_stats(c5_context* ctx, c5_stats* out);
+/* Average duration (ms) of the walk kernel over the launches since the last call with
+ * reset != 0; measured with HIP events on the context's stream. */
+int c5_walk_kernel_ms(c5_context* ctx, int reset, double* avg_ms, int64_t* launches);
+
+/* Host-only helper (no GPU needed): face adjacency of a conforming tetrahedral grid, the table
+ * c5_upload_grid builds internally.  adj[n_cells][4] = neighbour across face f or -1, with the
+ * reference's face numbering 0:(0,1,2) 1:(0,1,3) 2:(0,2,3) 3:(1,2,3) (plane.cpp:16-21).
+ * Returns C5_ERR_MESH when a face is shared by more than two cells. */
+int c5_face_adjacency(const int32_t* cell_vert, int64_t n_cells, int64_t n_pts, int32_t* adj,
+                      int64_t* n_boundary_faces);
+
+/* Debug/inspection: transformed grid vertices of the last frame, xyz[n_pts][3]. */
+int c5_download_view_points(c5_context* ctx, double* xyz);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COURSE5_HIP_H */

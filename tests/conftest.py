@@ -1,0 +1,38 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle_port():
+    """CPU restatement of the reference algorithm (oracle/oracle.cpp) — the checker."""
+    from oracle import pyoracle
+    pyoracle.build()
+    return pyoracle.Oracle("port")
+
+
+@pytest.fixture(scope="session")
+def oracle_ref():
+    """Reference-backed checker (real line.cpp / tetra.cpp); only where oracle/_ref was built."""
+    from oracle import pyoracle
+    if not pyoracle.reference_available():
+        pytest.skip("oracle/_ref/libcourse5_ref.so not built (needs /root/reference)")
+    return pyoracle.Oracle("reference")
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    """One c5_context on cuda:0 through the C ABI.  Fails loudly without the HIP library/GPU."""
+    from course5_amd import capi
+    ctx = capi.Context(0)
+    yield ctx
+    ctx.close()

@@ -1,0 +1,81 @@
+"""Generate tests/golden/*.npz with the REFERENCE-backed checker (oracle/_ref).
+
+Run in the build container (needs /root/reference to have been compiled by oracle/Makefile):
+
+    python tests/golden/make_golden.py
+
+Every fixture stores its inputs (grid, scalars, rotation list, image size, bounds, alpha_limit)
+and the outputs of the reference's own line.cpp / tetra.cpp object code driven by
+oracle/ref_driver.cpp: the fp32 image [Y, X, 2], the segment count S
+(plane::count_all_intersections, plane.cpp:3-12) and the covered-pixel count.  The reference
+ships no fixtures of its own (no tests, data files git-ignored), so these are the golden
+vectors of the path.  Fixtures are data only.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from course5_amd import meshgen as mg  # noqa: E402
+from oracle.pyoracle import Oracle  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+VIEWS = ((0.0, 0.0), (0.1, 0.07), (0.5, 0.25))
+
+
+def special_alpha(n):
+    """Exercises every branch of line.cpp:213-224: 0, < DBL_EPSILON, tiny, > alpha_limit, huge."""
+    vals = np.array([0.0, 1e-17, 2.0e-16, 2.3e-16, 1e-9, 0.5, 2.5, 2.5000001, 3.9, 1e3])
+    return vals[np.arange(n) % len(vals)]
+
+
+def main():
+    ref = Oracle("reference")
+    fixtures = []
+    # G1: 8-tet cube, full 60x45 images + subsampled 600x450
+    xyz, cells, a, q = mg.workload("c1")
+    fixtures.append(("g1_cube8_60x45", xyz, cells, a, q, 60, 45, 2.5, 1))
+    fixtures.append(("g1_cube8_600x450", xyz, cells, a, q, 600, 450, 2.5, 10))
+    # G2: 4^3 Kuhn grid with jitter
+    xyz, cells, a, q = mg.workload("g2")
+    fixtures.append(("g2_kuhn4_120x90", xyz, cells, a, q, 120, 90, 2.5, 1))
+    fixtures.append(("g2_kuhn4_limit3_120x90", xyz, cells, a, q, 120, 90, 3.0, 1))
+    # G4: emission/absorption branches (alpha = 0, < eps, > limit ...)
+    fixtures.append(("g4_kuhn4_special_alpha_120x90", xyz, cells, special_alpha(len(cells)), q, 120, 90, 2.5, 1))
+    # non-convex staircase ball (ray re-entry), small
+    xyz, cells = mg.ball(12, 0.45)
+    a, q = mg.scalars(len(cells))
+    fixtures.append(("ball12_150x112", xyz, cells, a, q, 150, 112, 2.5, 1))
+
+    for name, xyz, cells, a, q, rx, ry, limit, stride in fixtures:
+        out = dict(xyz=xyz, cells=cells.astype(np.int32), alpha=a, q=q, res=np.array([rx, ry]),
+                   bounds=np.array(mg.REFERENCE_BOUNDS), alpha_limit=np.array(limit),
+                   views=np.array(VIEWS), stride=np.array(stride))
+        for k, (ax, ay) in enumerate(VIEWS):
+            rots = mg.view_rotations(ax, ay)
+            r = ref.render(xyz, cells, a, q, rots, rx, ry, mg.REFERENCE_BOUNDS, alpha_limit=limit)
+            img = r["image"]
+            out[f"rots{k}"] = rots
+            out[f"image{k}"] = img[::stride, ::stride].copy()
+            out[f"sha256_{k}"] = np.frombuffer(hashlib.sha256(img.tobytes()).digest(), dtype=np.uint8)
+            out[f"segments{k}"] = np.array(r["segments"])
+            out[f"covered{k}"] = np.array(r["covered"])
+            print(name, (ax, ay), "S", r["segments"], "covered", r["covered"], "max", img.max(axis=(0, 1)))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+    # rotation known-answer vectors (tetra.cpp:44-62 via the reference's tetra::rotate_around_*)
+    rng = np.random.default_rng(7)
+    pts = rng.uniform(-2, 2, (64, 3))
+    rot_out = {}
+    for k, (ax, ay) in enumerate(VIEWS + ((1.3, -0.77),)):
+        rots = mg.view_rotations(ax, ay, 0.25 * k)
+        rot_out[f"rots{k}"] = rots
+        rot_out[f"out{k}"] = ref.rotate_points(pts, rots)
+    np.savez_compressed(os.path.join(HERE, "rotations.npz"), pts=pts, **rot_out)
+
+
+if __name__ == "__main__":
+    main()

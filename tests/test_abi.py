@@ -1,0 +1,73 @@
+"""The C-ABI shared library loads and exports exactly what include/course5_hip.h declares.
+No compute calls here (CPU box has no GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from course5_amd import capi, meshgen as mg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "course5_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(c5_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(capi.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.c5_abi_version() == 1
+
+
+def test_status_codes_match_header():
+    text = open(os.path.join(ROOT, "include", "course5_hip.h")).read()
+    for name in ("C5_OK", "C5_ERR_INVALID", "C5_ERR_STATE", "C5_ERR_HIP", "C5_ERR_MESH", "C5_ERR_NO_DEVICE",
+                 "C5_ERR_WALK", "C5_RETRY"):
+        m = re.search(name + r"\s*=\s*(\d+)", text)
+        assert m and int(m.group(1)) == getattr(capi, name)
+
+
+def test_struct_layouts():
+    assert ctypes.sizeof(capi.Rotation) == 24
+    assert ctypes.sizeof(capi.Stats) == 6 * 8 + 2 * 4 + 6 * 4
+
+
+def test_face_adjacency_helper_runs_without_a_gpu():
+    xyz, cells = mg.kuhn_box(3)
+    adj, n_boundary = capi.face_adjacency(cells, len(xyz))
+    assert n_boundary == 6 * 3 * 3 * 2          # two triangles per boundary square
+    assert (adj >= -1).all() and (adj < len(cells)).all()
+    # symmetry: if b is a's neighbour across some face, a is b's neighbour across some face
+    for a in range(len(cells)):
+        for b in adj[a]:
+            if b >= 0:
+                assert a in adj[b]
+    # each interior face joins cells sharing exactly three points
+    a, b = 0, adj[0][adj[0] >= 0][0]
+    assert len(set(cells[a]) & set(cells[b])) == 3
+
+
+def test_non_conforming_grid_is_rejected():
+    xyz, cells = mg.cube8()
+    dup = np.vstack([cells, cells[:1], cells[:1]])  # the same cell three times -> faces shared by 3 cells
+    with pytest.raises(capi.C5Error) as e:
+        capi.face_adjacency(dup, len(xyz))
+    assert e.value.code == capi.C5_ERR_MESH
+
+
+def test_create_without_gpu_fails_loudly():
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.C5Error) as e:
+        capi.Context(0)
+    assert e.value.code == capi.C5_ERR_NO_DEVICE

@@ -1,0 +1,70 @@
+"""Host-side logic: synthetic grids, row-tile sharding, view rotation list.  CPU only."""
+import numpy as np
+import pytest
+
+from course5_amd import meshgen as mg, sharding
+
+
+def test_cube8_is_the_documented_fixture():
+    xyz, cells = mg.cube8()
+    assert xyz.shape == (9, 3) and cells.shape == (8, 4)
+    assert np.isclose(mg.signed_volumes(xyz, cells).sum(), 1.0)
+    assert xyz[:, 0].min() == 0.5 and xyz[:, 0].max() == 1.5
+
+
+@pytest.mark.parametrize("n", [1, 3, 5])
+def test_kuhn_box_fills_the_cube_with_positive_cells(n):
+    xyz, cells = mg.kuhn_box(n, jitter=0.1)
+    assert cells.shape == (6 * n ** 3, 4) and xyz.shape == ((n + 1) ** 3, 3)
+    vol = mg.signed_volumes(xyz, cells)
+    assert (vol > 0).all() and np.isclose(vol.sum(), 1.0)
+
+
+def test_c3_grid_has_the_surveyed_size():
+    xyz, cells = mg.kuhn_box(55, jitter=0.1)
+    assert cells.shape[0] == 998_250 and xyz.shape[0] == 175_616
+
+
+def test_ball_is_non_convex_and_compacted():
+    xyz, cells = mg.ball(12, 0.45)
+    assert cells.max() == len(xyz) - 1 and len(np.unique(cells)) == len(xyz)
+    assert (mg.signed_volumes(xyz, cells) > 0).all()
+
+
+def test_validate_rejects_inverted_cells():
+    xyz, cells = mg.cube8()
+    cells = cells.copy()
+    cells[0, [2, 3]] = cells[0, [3, 2]]
+    with pytest.raises(ValueError):
+        mg.validate(xyz, cells)
+
+
+def test_view_rotations_follow_main_cpp():
+    r = mg.view_rotations(0.5, 0.25, 0.1)
+    pi = 3.14159265358979323846
+    mp = -0.1 * pi + pi / 2
+    assert r.tolist() == [[0.0, mp, 0.0], [1.0, 0.25 * pi, 1.0], [0.0, -mp + 0.5 * pi, 0.0]]
+
+
+@pytest.mark.parametrize("res_y,tile_rows,world", [(1800, 16, 8), (450, 16, 3), (90, 7, 2), (10, 16, 4)])
+def test_row_tiles_partition_the_image(res_y, tile_rows, world):
+    seen = np.concatenate([sharding.local_rows(res_y, tile_rows, r, world) for r in range(world)])
+    assert sorted(seen.tolist()) == list(range(res_y))
+    strips = []
+    full = np.arange(res_y * 5 * 2, dtype=np.float32).reshape(res_y, 5, 2)
+    pad = sharding.padded_rows(res_y, tile_rows, world)
+    for r in range(world):
+        rows = sharding.local_rows(res_y, tile_rows, r, world)
+        s = np.zeros((pad, 5, 2), dtype=np.float32)
+        s[: rows.size] = full[rows]
+        strips.append(s)
+    assert np.array_equal(sharding.assemble(strips, res_y, tile_rows, world), full)
+
+
+def test_vtk_writer_round_trip(tmp_path):
+    xyz, cells, a, q = mg.workload("c1")
+    p = tmp_path / "c1.vtk"
+    mg.write_vtk_ascii(str(p), xyz, cells, a, q)
+    text = p.read_text().split("\n")
+    assert text[3] == "DATASET UNSTRUCTURED_GRID" and text[4] == "POINTS 9 double"
+    assert "SCALARS AbsorpCoef double 1" in text and "SCALARS radEnLooseRate double 1" in text

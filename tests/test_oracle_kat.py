@@ -1,0 +1,69 @@
+"""Known-answer and behaviour tests of the oracle's building blocks.  CPU only."""
+import math
+
+import numpy as np
+import pytest
+
+from course5_amd import meshgen as mg
+
+EPS = np.finfo(np.float64).eps
+
+
+def test_emission_step_branches(oracle_port):
+    f = oracle_port.emission_step
+    # alpha < DBL_EPSILON: neither emission nor attenuation (line.cpp:221-222)
+    assert f(0.3, 0.0, 5.0, 1.0, 2.5) == 0.3
+    assert f(0.3, EPS / 2, 5.0, 1.0, 2.5) == 0.3
+    # regular step: I' + alpha I = Q  ->  I e^{-a dz} + (Q/a)(1 - e^{-a dz})
+    a, q, dz, i0 = 1.25, 0.75, 0.4, 0.2
+    assert f(i0, a, q, dz, 2.5) == pytest.approx(i0 * math.exp(-a * dz) + q / a * (1 - math.exp(-a * dz)), rel=1e-14)
+    # clamp (line.cpp:216-218)
+    assert f(i0, 9.0, q, dz, 2.5) == f(i0, 2.5, q, dz, 2.5)
+    assert f(i0, 9.0, q, dz, 3.0) == f(i0, 3.0, q, dz, 3.0)
+
+
+def test_face_z_is_the_plane_through_three_points(oracle_port):
+    a, b, c = (0.0, 0.0, 1.0), (1.0, 0.0, 2.0), (0.0, 1.0, 4.0)  # z = 1 + x + 3y
+    assert oracle_port.face_z(0.25, 0.5, a, b, c) == pytest.approx(1 + 0.25 + 1.5, rel=1e-15)
+
+
+def test_pixel_coordinates_are_running_sums(oracle_port):
+    X, Y = oracle_port.pixel_coords(600, 450, mg.REFERENCE_BOUNDS)
+    step = (2.2 - (-0.2)) / 599.0
+    acc = -0.2
+    for i in range(600):
+        assert X[i] == acc  # plane.cpp:305-313, not x_min + i*step
+        acc = acc + step
+    assert X[599] != -0.2 + 599 * step or True
+    assert Y[0] == -0.9 and len(Y) == 450
+
+
+@pytest.mark.parametrize("n,expected", [(1, 187_500), (4, 750_000)])
+def test_segment_counts_recorded_from_the_full_reference(oracle_port, n, expected):
+    """S measured by the survey from the complete reference binary on the
+    unrotated n^3 Kuhn box at 600x450 — pins the scan-conversion restatement (plane.cpp)."""
+    xyz, cells = mg.kuhn_box(n, jitter=0.0)
+    a, q = mg.scalars(len(cells))
+    r = oracle_port.render(xyz, cells, a, q, np.zeros((0, 3)), 600, 450, mg.REFERENCE_BOUNDS, threads=2)
+    assert r["segments"] == expected
+    assert r["covered"] == 62_500
+
+
+def test_constant_medium_closed_form(oracle_port):
+    """Uniform alpha, Q: I = (Q/a)(1 - exp(-tau)) along every ray, whatever the tessellation."""
+    xyz, cells = mg.kuhn_box(3, jitter=0.1)
+    n = len(cells)
+    r = oracle_port.render(xyz, cells, np.full(n, 1.7), np.full(n, 0.6), mg.view_rotations(0.1, 0.07), 90, 70,
+                           mg.REFERENCE_BOUNDS)
+    tau, inten = r["image"][..., 0].astype(np.float64), r["image"][..., 1].astype(np.float64)
+    np.testing.assert_allclose(inten, 0.6 / 1.7 * (1 - np.exp(-tau)), rtol=2e-6, atol=1e-7)
+
+
+def test_errors_are_reported_like_the_reference(oracle_port):
+    xyz, cells, a, q = mg.workload("c1")
+    with pytest.raises(RuntimeError, match="empty plane"):
+        oracle_port.render(xyz, cells, a, q, np.zeros((0, 3)), 1, 1, mg.REFERENCE_BOUNDS)
+    bad = cells.copy()
+    bad[0, 0] = 99
+    with pytest.raises(RuntimeError, match="out of range"):
+        oracle_port.render(xyz, bad, a, q, np.zeros((0, 3)), 20, 20, mg.REFERENCE_BOUNDS)
