@@ -68,9 +68,10 @@ def build_cli(verbose: bool = False, force: bool = False) -> str | None:
     srcs = sorted(os.path.join(host_dir, f) for f in os.listdir(host_dir) if f.endswith(".cpp"))
     deps = srcs + [os.path.join(host_dir, f) for f in os.listdir(host_dir) if f.endswith(".hpp")] + [LIB]
     if force or _newer(CLI, deps):
-        _run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-fopenmp", "-I", os.path.join(PKG, "..", "include"),
-              "-I", host_dir, "-o", CLI] + srcs +
-             [f"-L{PKG}", "-lcourse5_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-pthread"], verbose)
+        _run(["g++", "-O3", "-std=c++17", "-Wall", "-Wextra", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(PKG, "..", "include"),
+              "-I", "/opt/rocm/include", "-I", host_dir, "-o", CLI] + srcs +
+             [f"-L{PKG}", "-lcourse5_hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN",
+              "-Wl,-rpath,/opt/rocm/lib", "-pthread"], verbose)
     return CLI
 
 

@@ -1,0 +1,156 @@
+// `course` — command line of the MI355X build.  Same options, banner, timing lines, input and
+// output contract as the reference's project/src/main.cpp; the per-pixel OpenMP loops behind
+// `plane` are replaced by the HIP kernels in libcourse5_hip.so.
+#include <chrono>
+#include <cstdio>
+#include <memory>
+#include <iostream>
+#include <stdexcept>
+#include <thread>
+
+#include "cli.hpp"
+#include "config.hpp"
+#include "plane.hpp"
+#include "scene.hpp"
+
+namespace {
+const auto& timestamp = std::chrono::high_resolution_clock::now;
+
+long long ms_between(std::chrono::high_resolution_clock::time_point a, std::chrono::high_resolution_clock::time_point b) {
+    return std::chrono::duration_cast<std::chrono::milliseconds>(b - a).count();
+}
+
+std::string frame_name(const std::string& destination, std::size_t k, std::size_t frames) {
+    if (frames <= 1) return destination;
+    const auto dot = destination.rfind('.');
+    char tag[32];
+    std::snprintf(tag, sizeof tag, "_%05zu", k);
+    return dot == std::string::npos ? destination + tag : destination.substr(0, dot) + tag + destination.substr(dot);
+}
+}  // namespace
+
+int main(int argc, char** argv) try {
+    const render_config& config = app::instance().config;
+    if (!program_options(argc, argv, std::cout)) return 0;  // main.cpp:74-78
+
+    const std::vector<double> domain(DOMAIN_BOUNDS, DOMAIN_BOUNDS + 4);  // main.cpp:83
+
+    // main.cpp:85-92
+    std::cout << "Defined grid resolution: " << config.resolution_x << "x" << config.resolution_y << std::endl;
+    std::cout << "Source file: " << config.file << std::endl;
+    std::cout << "Number of parallel threads: " << config.threads << std::endl;
+    std::cout << "Initial rotate angle of roche lobe: " << config.donor_angle << " Pi" << std::endl;
+    std::cout << "Plane angle around x: " << config.angle_around_x << " Pi" << std::endl;
+    std::cout << "Plane angle around y: " << config.angle_around_y << " Pi" << std::endl;
+    std::cout << "Initial system angle around y: " << config.system_initial_angle_around_y << " Pi" << std::endl;
+    std::cout << "Limit alpha value: " << config.limit_alpha_value << std::endl;
+
+    render_config view = config;  // angles that a sweep advances
+    auto apply_view = [&](object3d_base& disk, object3d_base* lobe) {
+        // main.cpp:96,105-107 and 112-114; the lobe first turns by the donor angle (object3d_roche_lobe.cpp:48)
+        const double make_perpendicular_to_y_angle = -view.system_initial_angle_around_y * PI + PI / 2.;
+        auto three = [&](object3d_base& o) {
+            o.rotate_around_x_axis(make_perpendicular_to_y_angle);
+            o.rotate_around_y_axis(view.angle_around_y * PI, ACC_X0);
+            o.rotate_around_x_axis(-make_perpendicular_to_y_angle + view.angle_around_x * PI);
+        };
+        disk.clear_rotations();
+        three(disk);
+        if (lobe) {
+            lobe->clear_rotations();
+            lobe->rotate_around_y_axis(view.donor_angle * PI, ACC_X0);
+            three(*lobe);
+        }
+    };
+
+    auto t1 = timestamp();
+    object3d_accretion_disk acc_disk{};
+    std::string load_error;
+    std::thread acc_t([&]() {  // the file is parsed while the solids are generated (main.cpp:98-108)
+        try {
+            acc_disk = object3d_accretion_disk{config.file};
+        } catch (const std::exception& e) {
+            load_error = e.what();
+        }
+    });
+    std::vector<object3d_base> objects;
+    std::unique_ptr<object3d_roche_lobe> roche_lobe;
+    std::unique_ptr<object3d_sphere> acc_sphere;
+    if (!config.no_solids) {
+        roche_lobe = std::make_unique<object3d_roche_lobe>(point{ACC_X0, ACC_Y0, ACC_Z0}, L, config.donor_angle * PI,
+                                                           M_ACC, M_DONOR, OMEGA);
+        acc_sphere = std::make_unique<object3d_sphere>(point{ACC_X0, ACC_Y0, ACC_Z0}, ACC_DISK_R);  // never rotated (main.cpp:116)
+    }
+    acc_t.join();
+    if (!load_error.empty()) throw std::runtime_error(load_error);
+    apply_view(acc_disk, roche_lobe.get());
+    auto t2 = timestamp();
+    std::cout << "Loading data with VTK lib and other preparations completed in " << ms_between(t1, t2) << " ms. "
+              << std::endl;
+
+    if (!config.dump_solids.empty()) {
+        std::FILE* f = std::fopen(config.dump_solids.c_str(), "wb");
+        if (!f) throw std::runtime_error("cannot write '" + config.dump_solids + "'");
+        for (object3d_base* o : {static_cast<object3d_base*>(roche_lobe.get()), static_cast<object3d_base*>(acc_sphere.get())}) {
+            if (!o) continue;
+            const object3d_data& d = *o->get_pointer();
+            const long long n = static_cast<long long>(d.soup.size() / 12);
+            std::fwrite(&n, sizeof n, 1, f);
+            std::fwrite(d.soup.data(), sizeof(double), d.soup.size(), f);
+        }
+        std::fclose(f);
+    }
+    if (config.parse_only) {
+        const object3d_data& d = *acc_disk.get_pointer();
+        double sa = 0, sq = 0;
+        for (double v : d.value0) sa += v;
+        for (double v : d.value1) sq += v;
+        std::printf("grid: %zu points, %zu cells, sum(alpha) = %.17g, sum(Q) = %.17g\n", d.points.size() / 3, d.size(), sa, sq);
+        if (roche_lobe) std::printf("roche lobe: %zu solid cells\n", roche_lobe->get_pointer()->size());
+        if (acc_sphere) std::printf("sphere: %zu solid cells\n", acc_sphere->get_pointer()->size());
+        return 0;
+    }
+
+    objects.push_back(acc_disk);
+    if (roche_lobe) objects.push_back(*roche_lobe);
+    if (acc_sphere) objects.push_back(*acc_sphere);
+
+    t1 = timestamp();
+    plane base_plane{config.resolution_x, config.resolution_y, objects, domain, config.device};
+    base_plane.find_intersections();
+    object2d result = base_plane.trace_rays(tetra_value::alpha, tetra_value::Q);
+    t2 = timestamp();
+    std::cout << "Ray-tracing completed in " << ms_between(t1, t2) << " ms. " << std::endl;  // main.cpp:131-135
+
+    result.export_to_vti(frame_name(config.destination, 0, config.frames));
+    if (config.print_stats) {
+        const c5_stats st = base_plane.stats();
+        std::cout << "GPU frame: " << st.ms_total << " ms (transform " << st.ms_transform << ", records " << st.ms_records
+                  << ", entries " << st.ms_entries << ", solids " << st.ms_solids << ", walk " << st.ms_walk << "); "
+                  << st.segments << " segments, " << st.covered_pixels << " covered pixels, " << st.solid_pixels
+                  << " solid pixels" << std::endl;
+    }
+
+    // sweep: the grid, its adjacency and the solids stay on the GPU; only rotation lists change
+    for (std::size_t k = 1; k < config.frames; ++k) {
+        double* angle = config.sweep == "X"   ? &view.angle_around_x
+                        : config.sweep == "D" ? &view.donor_angle
+                        : config.sweep == "I" ? &view.system_initial_angle_around_y
+                                              : &view.angle_around_y;
+        *angle += config.sweep_step;
+        apply_view(objects[0], roche_lobe ? &objects[1] : nullptr);
+        base_plane.update_views(objects);
+        base_plane.find_intersections();
+        base_plane.trace_rays(tetra_value::alpha, tetra_value::Q).export_to_vti(frame_name(config.destination, k, config.frames));
+    }
+    if (config.frames > 1) {
+        const auto t3 = timestamp();
+        std::cout << config.frames - 1 << " further frames in " << ms_between(t2, t3) << " ms. " << std::endl;
+    }
+    std::cout << "Result exported. Calculations completed." << std::endl;
+    return 0;
+} catch (const std::exception& e) {
+    // the reference lets std::runtime_error escape and abort; report and fail instead
+    std::cerr << "course: " << e.what() << std::endl;
+    return 1;
+}

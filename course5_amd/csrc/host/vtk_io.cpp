@@ -1,0 +1,298 @@
+#include "vtk_io.hpp"
+
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+namespace {
+
+std::string lower(std::string s) {
+    std::transform(s.begin(), s.end(), s.begin(), [](unsigned char c) { return static_cast<char>(std::tolower(c)); });
+    return s;
+}
+
+// Cursor over the whole file: whitespace-separated tokens for the ASCII parts, raw big-endian
+// blocks for BINARY data sections.
+class cursor {
+public:
+    explicit cursor(std::string data) : buf_(std::move(data)) {}
+    bool eof() {
+        skip_ws();
+        return pos_ >= buf_.size();
+    }
+    std::string line() {
+        const size_t e = buf_.find('\n', pos_);
+        std::string s = buf_.substr(pos_, e == std::string::npos ? std::string::npos : e - pos_);
+        pos_ = (e == std::string::npos) ? buf_.size() : e + 1;
+        if (!s.empty() && s.back() == '\r') s.pop_back();
+        return s;
+    }
+    std::string token() {
+        skip_ws();
+        const size_t b = pos_;
+        while (pos_ < buf_.size() && !std::isspace(static_cast<unsigned char>(buf_[pos_]))) ++pos_;
+        if (b == pos_) throw std::runtime_error("vtk: unexpected end of file");
+        return buf_.substr(b, pos_ - b);
+    }
+    std::string peek() {
+        const size_t save = pos_;
+        std::string t = eof() ? std::string() : token();
+        pos_ = save;
+        return t;
+    }
+    void rest_of_line() {
+        while (pos_ < buf_.size() && buf_[pos_] != '\n') ++pos_;
+        if (pos_ < buf_.size()) ++pos_;
+    }
+    const unsigned char* raw(size_t n) {
+        if (pos_ + n > buf_.size()) throw std::runtime_error("vtk: binary section runs past the end of the file");
+        const unsigned char* p = reinterpret_cast<const unsigned char*>(buf_.data()) + pos_;
+        pos_ += n;
+        return p;
+    }
+
+private:
+    void skip_ws() {
+        while (pos_ < buf_.size() && std::isspace(static_cast<unsigned char>(buf_[pos_]))) ++pos_;
+    }
+    std::string buf_;
+    size_t pos_ = 0;
+};
+
+size_t type_size(const std::string& t) {
+    if (t == "bit") throw std::runtime_error("vtk: bit arrays are not supported");
+    if (t == "char" || t == "unsigned_char") return 1;
+    if (t == "short" || t == "unsigned_short") return 2;
+    if (t == "int" || t == "unsigned_int" || t == "float" || t == "vtktypeint32" || t == "vtktypeuint32") return 4;
+    if (t == "long" || t == "unsigned_long" || t == "double" || t == "vtktypeint64" || t == "vtktypeuint64" ||
+        t == "vtkidtype")
+        return 8;
+    throw std::runtime_error("vtk: unknown data type '" + t + "'");
+}
+
+template <class T>
+T from_big_endian(const unsigned char* p) {
+    unsigned char tmp[sizeof(T)];
+    for (size_t k = 0; k < sizeof(T); ++k) tmp[k] = p[sizeof(T) - 1 - k];
+    T v;
+    std::memcpy(&v, tmp, sizeof(T));
+    return v;
+}
+
+double binary_value(const std::string& t, const unsigned char* p) {
+    if (t == "char") return static_cast<double>(static_cast<signed char>(*p));
+    if (t == "unsigned_char") return static_cast<double>(*p);
+    if (t == "short") return from_big_endian<int16_t>(p);
+    if (t == "unsigned_short") return from_big_endian<uint16_t>(p);
+    if (t == "int" || t == "vtktypeint32") return from_big_endian<int32_t>(p);
+    if (t == "unsigned_int" || t == "vtktypeuint32") return from_big_endian<uint32_t>(p);
+    if (t == "float") return from_big_endian<float>(p);
+    if (t == "double") return from_big_endian<double>(p);
+    if (t == "unsigned_long" || t == "vtktypeuint64") return static_cast<double>(from_big_endian<uint64_t>(p));
+    return static_cast<double>(from_big_endian<int64_t>(p));  // long, vtktypeint64, vtkidtype
+}
+
+// n values of `type` into doubles (ids up to 2^53 survive the trip)
+std::vector<double> read_array(cursor& c, bool binary, const std::string& type_in, size_t n) {
+    const std::string type = lower(type_in);
+    std::vector<double> out(n);
+    if (binary) {
+        c.rest_of_line();
+        const size_t sz = type_size(type);
+        const unsigned char* p = c.raw(n * sz);
+        for (size_t i = 0; i < n; ++i) out[i] = binary_value(type, p + i * sz);
+    } else {
+        for (size_t i = 0; i < n; ++i) {
+            const std::string t = c.token();
+            char* end = nullptr;
+            out[i] = std::strtod(t.c_str(), &end);
+            if (end == t.c_str()) throw std::runtime_error("vtk: expected a number, found '" + t + "'");
+        }
+    }
+    return out;
+}
+
+size_t to_count(const std::string& t) {
+    char* end = nullptr;
+    const long long v = std::strtoll(t.c_str(), &end, 10);
+    if (end == t.c_str() || v < 0) throw std::runtime_error("vtk: expected a count, found '" + t + "'");
+    return static_cast<size_t>(v);
+}
+
+void skip_metadata(cursor& c) {  // METADATA block ends at an empty line
+    c.rest_of_line();
+    while (!c.eof()) {
+        const std::string l = c.line();
+        if (l.find_first_not_of(" \t") == std::string::npos) break;
+    }
+}
+
+}  // namespace
+
+vtk_grid read_legacy_vtk(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open '" + path + "'");
+    std::stringstream ss;
+    ss << f.rdbuf();
+    cursor c(ss.str());
+
+    const std::string magic = c.line();
+    if (magic.rfind("# vtk DataFile Version", 0) != 0) throw std::runtime_error("vtk: not a legacy VTK file: " + path);
+    c.line();  // title
+    const std::string mode = lower(c.token());
+    if (mode != "ascii" && mode != "binary") throw std::runtime_error("vtk: expected ASCII or BINARY");
+    const bool binary = (mode == "binary");
+
+    vtk_grid g;
+    size_t n_cells = 0;
+    enum class section { none, cell, point } where = section::none;
+    size_t section_count = 0;
+
+    while (!c.eof()) {
+        const std::string key = lower(c.token());
+        if (key == "dataset") {
+            const std::string kind = lower(c.token());
+            if (kind != "unstructured_grid") throw std::runtime_error("vtk: DATASET " + kind + " is not an unstructured grid");
+        } else if (key == "points") {
+            const size_t n = to_count(c.token());
+            const std::string type = c.token();
+            g.points = read_array(c, binary, type, 3 * n);
+        } else if (key == "cells") {
+            const size_t a = to_count(c.token());
+            const size_t b = to_count(c.token());
+            std::vector<double> offsets, conn;
+            if (lower(c.peek()) == "offsets") {  // 5.1 layout: CELLS n+1 m / OFFSETS type / CONNECTIVITY type
+                c.token();
+                offsets = read_array(c, binary, c.token(), a);
+                if (lower(c.token()) != "connectivity") throw std::runtime_error("vtk: CONNECTIVITY expected");
+                conn = read_array(c, binary, c.token(), b);
+                n_cells = a ? a - 1 : 0;
+                g.tets.resize(4 * n_cells);
+                for (size_t k = 0; k < n_cells; ++k) {
+                    const size_t lo = static_cast<size_t>(offsets[k]), hi = static_cast<size_t>(offsets[k + 1]);
+                    if (hi - lo < 4 || hi > conn.size()) throw std::runtime_error("vtk: a cell has fewer than four points");
+                    for (int v = 0; v < 4; ++v) g.tets[4 * k + v] = static_cast<int32_t>(conn[lo + v]);
+                }
+            } else {  // classic: CELLS n size, then n records "k id0 ... id(k-1)"
+                n_cells = a;
+                const std::vector<double> raw = read_array(c, binary, "int", b);
+                g.tets.resize(4 * n_cells);
+                size_t p = 0;
+                for (size_t k = 0; k < n_cells; ++k) {
+                    if (p >= raw.size()) throw std::runtime_error("vtk: CELLS section is truncated");
+                    const size_t m = static_cast<size_t>(raw[p]);
+                    if (m < 4 || p + 1 + m > raw.size()) throw std::runtime_error("vtk: a cell has fewer than four points");
+                    for (int v = 0; v < 4; ++v) g.tets[4 * k + v] = static_cast<int32_t>(raw[p + 1 + v]);
+                    p += 1 + m;
+                }
+            }
+        } else if (key == "cell_types") {
+            const size_t n = to_count(c.token());
+            read_array(c, binary, "int", n);
+        } else if (key == "cell_data") {
+            where = section::cell;
+            section_count = to_count(c.token());
+        } else if (key == "point_data") {
+            where = section::point;
+            section_count = to_count(c.token());
+        } else if (key == "scalars") {
+            const std::string name = c.token();
+            const std::string type = c.token();
+            size_t ncomp = 1;
+            std::string nxt = c.peek();
+            if (!nxt.empty() && std::isdigit(static_cast<unsigned char>(nxt[0]))) ncomp = to_count(c.token());
+            if (lower(c.peek()) == "lookup_table") {
+                c.token();
+                c.token();
+            }
+            const std::vector<double> v = read_array(c, binary, type, ncomp * section_count);
+            if (where == section::cell) {
+                std::vector<double>& dst = g.cell_scalars[name];
+                dst.resize(section_count);
+                for (size_t k = 0; k < section_count; ++k) dst[k] = v[k * ncomp];
+            }
+        } else if (key == "lookup_table") {
+            c.token();
+            const size_t n = to_count(c.token());
+            if (binary) {
+                c.rest_of_line();
+                c.raw(4 * n);
+            } else {
+                for (size_t k = 0; k < 4 * n; ++k) c.token();
+            }
+        } else if (key == "vectors" || key == "normals") {
+            c.token();
+            read_array(c, binary, c.token(), 3 * section_count);
+        } else if (key == "texture_coordinates") {
+            c.token();
+            const size_t dim = to_count(c.token());
+            read_array(c, binary, c.token(), dim * section_count);
+        } else if (key == "tensors") {
+            c.token();
+            read_array(c, binary, c.token(), 9 * section_count);
+        } else if (key == "field") {
+            c.token();
+            const size_t n_arrays = to_count(c.token());
+            for (size_t a = 0; a < n_arrays; ++a) {
+                std::string name = c.token();
+                while (lower(name) == "metadata") {  // 5.x writes METADATA after arrays
+                    skip_metadata(c);
+                    name = c.token();
+                }
+                const size_t ncomp = to_count(c.token());
+                const size_t ntup = to_count(c.token());
+                const std::string type = c.token();
+                const std::vector<double> v = read_array(c, binary, type, ncomp * ntup);
+                if (where == section::cell && ntup == section_count && ncomp >= 1) {
+                    std::vector<double>& dst = g.cell_scalars[name];
+                    dst.resize(ntup);
+                    for (size_t k = 0; k < ntup; ++k) dst[k] = v[k * ncomp];
+                }
+            }
+        } else if (key == "metadata") {
+            skip_metadata(c);
+        } else {
+            throw std::runtime_error("vtk: unsupported keyword '" + key + "'");
+        }
+    }
+    if (g.points.empty() || g.tets.empty()) throw std::runtime_error("vtk: no POINTS or no CELLS in " + path);
+    const int64_t np = g.n_points();
+    for (int32_t id : g.tets)
+        if (id < 0 || id >= np) throw std::runtime_error("vtk: cell references a point id out of range");
+    for (auto& kv : g.cell_scalars)
+        if (kv.second.size() != n_cells) throw std::runtime_error("vtk: scalar array '" + kv.first + "' has the wrong length");
+    return g;
+}
+
+void write_vti(const std::string& path, const float* image, int res_x, int res_y) {
+    std::ofstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot write '" + path + "'");
+    const uint64_t n_values = static_cast<uint64_t>(res_x) * static_cast<uint64_t>(res_y) * 2u;
+    const uint64_t n_bytes = n_values * sizeof(double);
+    f << "<?xml version=\"1.0\"?>\n"
+      << "<VTKFile type=\"ImageData\" version=\"1.0\" byte_order=\"LittleEndian\" header_type=\"UInt64\">\n"
+      << "  <ImageData WholeExtent=\"0 " << res_x - 1 << " 0 " << res_y - 1 << " 0 0\" Origin=\"0 0 0\" Spacing=\"1 1 1\">\n"
+      << "    <Piece Extent=\"0 " << res_x - 1 << " 0 " << res_y - 1 << " 0 0\">\n"
+      << "      <PointData Scalars=\"ImageScalars\">\n"
+      << "        <DataArray type=\"Float64\" Name=\"ImageScalars\" NumberOfComponents=\"2\" format=\"appended\" offset=\"0\"/>\n"
+      << "      </PointData>\n"
+      << "      <CellData/>\n"
+      << "    </Piece>\n"
+      << "  </ImageData>\n"
+      << "  <AppendedData encoding=\"raw\">\n   _";
+    f.write(reinterpret_cast<const char*>(&n_bytes), sizeof n_bytes);
+    // fp32 results widened to the VTK_DOUBLE the reference allocates (object2d.cpp:13,17-21)
+    std::vector<double> row(static_cast<size_t>(res_x) * 2);
+    for (int y = 0; y < res_y; ++y) {
+        const float* src = image + static_cast<size_t>(y) * res_x * 2;
+        for (size_t k = 0; k < row.size(); ++k) row[k] = static_cast<double>(src[k]);
+        f.write(reinterpret_cast<const char*>(row.data()), static_cast<std::streamsize>(row.size() * sizeof(double)));
+    }
+    f << "\n  </AppendedData>\n</VTKFile>\n";
+    if (!f) throw std::runtime_error("error while writing '" + path + "'");
+}

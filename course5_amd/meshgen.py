@@ -182,3 +182,31 @@ def write_vtk_ascii(path: str, xyz: np.ndarray, cells: np.ndarray, alpha: np.nda
         for name, arr in (("AbsorpCoef", alpha), ("radEnLooseRate", q)):
             f.write(f"SCALARS {name} double 1\nLOOKUP_TABLE default\n")
             np.savetxt(f, arr, fmt="%.17g")
+
+
+def write_vtk_binary(path: str, xyz, cells, alpha, q, v51: bool = False) -> None:
+    """Legacy BINARY (big-endian) variant; v51=True uses the 5.1 OFFSETS/CONNECTIVITY cell layout."""
+    n_pts, n_cells = xyz.shape[0], cells.shape[0]
+    with open(path, "wb") as f:
+        f.write(("# vtk DataFile Version %s\nsynthetic tetrahedral grid\nBINARY\nDATASET UNSTRUCTURED_GRID\n"
+                 % ("5.1" if v51 else "3.0")).encode())
+        f.write(f"POINTS {n_pts} double\n".encode())
+        f.write(np.ascontiguousarray(xyz, dtype=">f8").tobytes())
+        f.write(b"\n")
+        if v51:
+            f.write(f"CELLS {n_cells + 1} {4 * n_cells}\nOFFSETS vtktypeint64\n".encode())
+            f.write((4 * np.arange(n_cells + 1)).astype(">i8").tobytes())
+            f.write(b"\nCONNECTIVITY vtktypeint64\n")
+            f.write(np.ascontiguousarray(cells).astype(">i8").tobytes())
+        else:
+            f.write(f"CELLS {n_cells} {5 * n_cells}\n".encode())
+            f.write(np.hstack([np.full((n_cells, 1), 4), cells]).astype(">i4").tobytes())
+        f.write(f"\nCELL_TYPES {n_cells}\n".encode())
+        f.write(np.full(n_cells, 10).astype(">i4").tobytes())
+        f.write(f"\nCELL_DATA {n_cells}\n".encode())
+        # the second array goes through FIELD data, which newer writers use for extra arrays
+        f.write(b"SCALARS AbsorpCoef double 1\nLOOKUP_TABLE default\n")
+        f.write(np.ascontiguousarray(alpha, dtype=">f8").tobytes())
+        f.write(f"\nFIELD FieldData 1\nradEnLooseRate 1 {n_cells} float\n".encode())
+        f.write(np.ascontiguousarray(q).astype(">f4").tobytes())
+        f.write(b"\n")
