@@ -30,8 +30,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from course5_amd import capi, meshgen as mg  # noqa: E402
-from course5_amd.pipeline import FramePipeline  # noqa: E402
+from course5_amd import capi, meshgen as mg, sharding  # noqa: E402
+from course5_amd.pipeline import FramePipeline, gather_row_costs  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 HBM_ACHIEVABLE_GBS = 6290.0  # measured float4 copy, same table
@@ -47,11 +47,18 @@ def parse():
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--workload", default="c3", help="c3 (998 250 tets, default), c2, kuhnN")
-    p.add_argument("--res", default="2400x1800")
+    p.add_argument("--res", default="2400x1800", help="image size of the N = 1 workload")
+    p.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                   help="N > 1: weak = per-GPU rays stay at --res (image grows by sqrt(N) per side; N = 4 is "
+                        "BASELINE config 4, 4800x3600); strong = the same --res frame split over N GPUs")
     p.add_argument("--tile", type=int, default=-1, help="wavefront tile shape override (0: 64x1, 1: 16x4, 2: 8x8)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-res", default="1200x900")
     p.add_argument("--pipeline-depth", type=int, default=2, help="N > 1: frames whose gather may be in flight")
+    p.add_argument("--sharding", choices=["blocks", "cyclic"], default="blocks",
+                   help="N > 1: contiguous cost-balanced row blocks (default) or cyclic 16-row tiles")
+    p.add_argument("--row-base-cost", type=float, default=0.5,
+                   help="blocks: fixed cost per pixel in segment units added when balancing")
     return p.parse_args()
 
 
@@ -105,6 +112,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     res_x, res_y = (int(v) for v in args.res.lower().split("x"))
+    base_res = (res_x, res_y)
+    if world > 1 and args.scaling == "weak":
+        res_x, res_y = int(round(res_x * world ** 0.5)), int(round(res_y * world ** 0.5))
     xyz, cells, alpha, q = mg.workload(args.workload)
     rots = mg.view_rotations(**mg.BENCH_VIEW)
 
@@ -112,8 +122,6 @@ def main():
     ctx = capi.Context(local_rank)
     ctx.upload_grid(xyz, cells, alpha, q)
     ctx.set_image(res_x, res_y, mg.REFERENCE_BOUNDS)
-    if world > 1:
-        ctx.set_row_tiles(TILE_ROWS, rank, world)
     ctx.set_view(rots)
     ctx.set_alpha_limit(2.5)
     ctx.set_option("stage_timing", 0)
@@ -121,11 +129,30 @@ def main():
         ctx.set_option("tile", args.tile)
     ctx.set_stream(stream.cuda_stream)
 
-    n_local = ctx.local_rows
-    pipe = FramePipeline(res_x, res_y, TILE_ROWS, rank, world, dev, depth=args.pipeline_depth)
-
     def render(strip):
         ctx.render_device(strip.data_ptr())
+
+    blocks = None
+    with torch.cuda.stream(stream):
+        if world > 1 and args.sharding == "cyclic":
+            ctx.set_row_tiles(TILE_ROWS, rank, world)
+        elif world > 1:
+            # one probe frame on equal blocks measures segments per row; every rank then derives the
+            # same cost-balanced contiguous blocks (pixels are independent: plane.cpp:161-169)
+            eq = sharding.equal_blocks(res_y, world)
+            ctx.set_row_range(*eq[rank])
+            ctx.set_option("row_costs", 1)
+            probe = torch.zeros((eq[rank][1], res_x, 2), dtype=torch.float32, device=dev)
+            render(probe)
+            while ctx.synchronize() == capi.C5_RETRY:
+                render(probe)
+            costs = gather_row_costs(ctx.row_costs(), eq, rank, world, dev)
+            blocks = sharding.balanced_blocks(costs, world, base_cost=res_x * args.row_base_cost)
+            ctx.set_option("row_costs", 0)
+            ctx.set_row_range(*blocks[rank])
+            del probe
+    n_local = ctx.local_rows
+    pipe = FramePipeline(res_x, res_y, rank, world, dev, depth=args.pipeline_depth, tile_rows=TILE_ROWS, blocks=blocks)
 
     with torch.cuda.stream(stream):
         # warm-up (also lets the entry buffer reach its size: C5_RETRY means "render again")
@@ -194,16 +221,22 @@ def main():
         out = {
             "metric": "Mrays/sec at 2400x1800 on 1M-tet grid", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: Kuhn box 55^3 = {cells.shape[0]} tets, {xyz.shape[0]} points, "
                                    f"jitter 0.1h, alpha~U[0,4) Q~U[0,1) seed 1234; {res_x}x{res_y}; view -X 0.1 -Y 0.07; "
                                    f"alpha_limit 2.5; no solids" if args.workload == "c3" else
                                    f"{args.workload}: {cells.shape[0]} tets; {res_x}x{res_y}",
                        "parallelism": "single GPU" if world == 1 else
-                                      f"row tiles of {TILE_ROWS} rows dealt cyclically to {world} ranks, grid replicated, "
-                                      f"one RCCL gather per frame to rank 0",
-                       "segments_per_frame": S_total, "pixels_per_frame": P_total},
+                                      (f"row tiles of {TILE_ROWS} rows dealt cyclically to {world} ranks" if blocks is None else
+                                       f"{world} contiguous row blocks balanced by measured segments per row "
+                                       f"(rows per rank {[n for _, n in blocks]})") +
+                                      ", grid replicated, one RCCL gather per frame to rank 0",
+                       "segments_per_frame": S_total, "pixels_per_frame": P_total,
+                       "rays_per_gpu": P_total // world,
+                       "scaling_note": None if world == 1 else
+                       (f"weak: {base_res[0]}x{base_res[1]} rays per GPU, image {res_x}x{res_y}" if args.scaling == "weak"
+                        else f"strong: one {res_x}x{res_y} frame split over {world} GPUs")},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

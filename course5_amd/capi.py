@@ -22,6 +22,7 @@ EXPORTS = [
     "c5_local_rows", "c5_set_view", "c5_set_solid_view", "c5_set_alpha_limit", "c5_set_option",
     "c5_render", "c5_render_device", "c5_synchronize", "c5_get_stats", "c5_walk_kernel_ms",
     "c5_download_view_points", "c5_face_adjacency", "c5_set_stream",
+    "c5_set_row_range", "c5_get_row_costs",
 ]
 
 
@@ -83,6 +84,8 @@ def load_library() -> C.CDLL:
     lib.c5_walk_kernel_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.c5_download_view_points.argtypes = [vp, dp]
     lib.c5_set_stream.argtypes = [vp, vp]
+    lib.c5_set_row_range.argtypes = [vp, C.c_int, C.c_int]
+    lib.c5_get_row_costs.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int]
     lib.c5_face_adjacency.argtypes = [ip, C.c_int64, C.c_int64, ip, C.POINTER(C.c_int64)]
     for name in EXPORTS:
         if name not in ("c5_destroy", "c5_last_error"):
@@ -171,6 +174,15 @@ class Context:
 
     def set_row_tiles(self, tile_rows: int, rank: int, world: int):
         self._check(self.lib.c5_set_row_tiles(self.handle, tile_rows, rank, world))
+
+    def set_row_range(self, row_begin: int, row_count: int = -1):
+        self._check(self.lib.c5_set_row_range(self.handle, row_begin, row_count))
+
+    def row_costs(self) -> np.ndarray:
+        """Segments per local row of the last frame (option "row_costs" must be on)."""
+        out = np.zeros(self.local_rows, dtype=np.uint32)
+        self._check(self.lib.c5_get_row_costs(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint32)), out.size))
+        return out
 
     @property
     def local_rows(self) -> int:

@@ -75,7 +75,10 @@ struct c5_context {
     double bounds[4] = {0, 0, 0, 0};
     c5::ImageParams im{};
     int cfg_tile_rows = 0, cfg_rank = 0, cfg_world = 1;
-    DeviceBuffer xtab, ytab, count, offs, scratch, entries, mask, out, counters;
+    int cfg_row_begin = 0, cfg_row_count = -1;  // -1: all rows
+    DeviceBuffer xtab, ytab, count, offs, scratch, entries, mask, out, counters, row_cost;
+    std::vector<double> host_ytab;
+    int row_costs = 0;
     int64_t entry_capacity = 0;
     c5::FrameCounters* host_counters = nullptr;  // pinned
 
@@ -151,6 +154,11 @@ int recompute_rows(c5_context* ctx) {
     im.tile_rows = (ctx->cfg_tile_rows > 0) ? ctx->cfg_tile_rows : (im.res_y > 0 ? im.res_y : 1);
     im.rank = ctx->cfg_rank;
     im.world = ctx->cfg_world;
+    im.row_begin = ctx->cfg_row_begin;
+    im.row_count = (ctx->cfg_row_count < 0) ? im.res_y - im.row_begin : ctx->cfg_row_count;
+    if (im.row_begin < 0 || im.row_count < 0 || im.row_begin + im.row_count > im.res_y)
+        return fail(ctx, C5_ERR_INVALID, "row range [%d, %d) outside the image of %d rows", im.row_begin,
+                    im.row_begin + im.row_count, im.res_y);
     int n = 0;
     for (int r = 0; r < im.res_y; ++r)
         if (c5::local_row_of(im, r) >= 0) ++n;
@@ -167,6 +175,7 @@ int ensure_image_buffers(c5_context* ctx) {
     C5_HIP(ctx, ctx->scratch.ensure(static_cast<size_t>(padded / 1024 + 1024) * sizeof(int32_t)));
     C5_HIP(ctx, ctx->mask.ensure(static_cast<size_t>(padded) * sizeof(uint32_t)));
     C5_HIP(ctx, ctx->out.ensure(static_cast<size_t>(padded) * sizeof(float) * 2));
+    C5_HIP(ctx, ctx->row_cost.ensure(static_cast<size_t>(im.n_local_rows + 64) * sizeof(uint32_t)));
     if (ctx->entry_capacity < 2 * n_px + 1024) {
         ctx->entry_capacity = 2 * n_px + 1024;
         C5_HIP(ctx, ctx->entries.ensure(static_cast<size_t>(ctx->entry_capacity) * sizeof(c5::Entry)));
@@ -215,6 +224,17 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     g.bface = ctx->bface.as<uint32_t>();
     g.rec = ctx->rec.as<c5::CellRecord>();
     g.opt = ctx->opt.as<c5::CellOptics>();
+    // y band of the rows this context renders (one pixel of slack on both sides)
+    if (im.n_local_rows > 0) {
+        const int first = c5::global_row_of(im, 0), last = c5::global_row_of(im, im.n_local_rows - 1);
+        const double pad = std::fabs(im.step_y);
+        const double ya = ctx->host_ytab[static_cast<size_t>(first)], yb = ctx->host_ytab[static_cast<size_t>(last)];
+        g.cull_y_lo = std::fmin(ya, yb) - pad;
+        g.cull_y_hi = std::fmax(ya, yb) + pad;
+    } else {
+        g.cull_y_lo = 1.0;
+        g.cull_y_hi = -1.0;
+    }
 
     // (a2) view transform
     c5::launch_transform_soa(s, g.px, g.py, g.pz, g.vx, g.vy, g.vz, g.n_pts, ctx->view);
@@ -279,6 +299,11 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     wp.xcd_mode = ctx->xcd_mode;
     wp.order = ctx->order;
     wp.counters = ctx->counters.as<c5::FrameCounters>();
+    wp.row_cost = nullptr;
+    if (ctx->row_costs && im.n_local_rows > 0) {
+        wp.row_cost = ctx->row_cost.as<uint32_t>();
+        C5_HIP(ctx, hipMemsetAsync(ctx->row_cost.ptr, 0, static_cast<size_t>(im.n_local_rows) * sizeof(uint32_t), s));
+    }
 
     int slot = -1;
     if (ctx->walk_timing) {
@@ -404,7 +429,7 @@ void c5_destroy(c5_context* ctx) {
     DeviceBuffer* bufs[] = {&ctx->px, &ctx->py, &ctx->pz, &ctx->vx, &ctx->vy, &ctx->vz, &ctx->cell_vert,
                             &ctx->cell_adj, &ctx->alpha, &ctx->q, &ctx->bface, &ctx->rec, &ctx->opt,
                             &ctx->xtab, &ctx->ytab, &ctx->count, &ctx->offs, &ctx->scratch, &ctx->entries,
-                            &ctx->mask, &ctx->out, &ctx->counters};
+                            &ctx->mask, &ctx->out, &ctx->counters, &ctx->row_cost};
     for (DeviceBuffer* b : bufs) b->release();
     for (Solid& s : ctx->solids) {
         s.raw.release();
@@ -470,6 +495,10 @@ int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int3
     C5_HIP(ctx, ctx->bface.ensure(bfaces.size() * 4 + 4));
     C5_HIP(ctx, ctx->rec.ensure(cb * sizeof(c5::CellRecord) + 128));
     C5_HIP(ctx, ctx->opt.ensure(cb * sizeof(c5::CellOptics) + 32));
+    // records of cells outside a context's row band are never rebuilt; keep whatever they hold a
+    // valid record (neighbour ids inside the grid) from the start
+    C5_HIP(ctx, hipMemset(ctx->rec.ptr, 0, ctx->rec.bytes));
+    C5_HIP(ctx, hipMemset(ctx->opt.ptr, 0, ctx->opt.bytes));
     if (n_pts > 0) {
         C5_HIP(ctx, hipMemcpy(ctx->px.ptr, sx.data(), pb, hipMemcpyHostToDevice));
         C5_HIP(ctx, hipMemcpy(ctx->py.ptr, sy.data(), pb, hipMemcpyHostToDevice));
@@ -559,8 +588,10 @@ int c5_set_image(c5_context* ctx, int res_x, int res_y, const double* bounds4) {
     C5_HIP(ctx, ctx->ytab.ensure(Y.size() * 8));
     C5_HIP(ctx, hipMemcpy(ctx->xtab.ptr, X.data(), X.size() * 8, hipMemcpyHostToDevice));
     C5_HIP(ctx, hipMemcpy(ctx->ytab.ptr, Y.data(), Y.size() * 8, hipMemcpyHostToDevice));
+    ctx->host_ytab = Y;
     ctx->have_image = true;
-    recompute_rows(ctx);
+    rc = recompute_rows(ctx);
+    if (rc) return rc;
     return ensure_image_buffers(ctx);
 }
 
@@ -576,9 +607,43 @@ int c5_set_row_tiles(c5_context* ctx, int tile_rows, int rank, int world) {
         int rc = bind_device(ctx);
         if (rc) return rc;
         C5_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        recompute_rows(ctx);
+        rc = recompute_rows(ctx);
+        if (rc) return rc;
         return ensure_image_buffers(ctx);
     }
+    return C5_OK;
+}
+
+int c5_set_row_range(c5_context* ctx, int row_begin, int row_count) {
+    if (!ctx) return fail(nullptr, C5_ERR_INVALID, "null context");
+    if (row_begin < 0 || row_count < -1) return fail(ctx, C5_ERR_INVALID, "bad row range");
+    const int old_begin = ctx->cfg_row_begin, old_count = ctx->cfg_row_count;
+    ctx->cfg_row_begin = row_begin;
+    ctx->cfg_row_count = row_count;
+    if (ctx->have_image) {
+        int rc = bind_device(ctx);
+        if (rc) return rc;
+        C5_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        rc = recompute_rows(ctx);
+        if (rc) {
+            ctx->cfg_row_begin = old_begin;
+            ctx->cfg_row_count = old_count;
+            recompute_rows(ctx);
+            return rc;
+        }
+        return ensure_image_buffers(ctx);
+    }
+    return C5_OK;
+}
+
+int c5_get_row_costs(c5_context* ctx, uint32_t* costs, int n_rows) {
+    if (!ctx || !costs) return fail(ctx, C5_ERR_INVALID, "null argument");
+    if (!ctx->row_costs) return fail(ctx, C5_ERR_STATE, "enable option \"row_costs\" before rendering");
+    if (n_rows != ctx->im.n_local_rows) return fail(ctx, C5_ERR_INVALID, "expected %d rows", ctx->im.n_local_rows);
+    int rc = c5_synchronize(ctx);
+    if (rc) return rc;
+    if (n_rows > 0)
+        C5_HIP(ctx, hipMemcpy(costs, ctx->row_cost.ptr, static_cast<size_t>(n_rows) * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return C5_OK;
 }
 
@@ -617,6 +682,8 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
         ctx->order = static_cast<int>(value) != 0;
     } else if (n == "xcd_mode") {
         ctx->xcd_mode = static_cast<int>(value) != 0;
+    } else if (n == "row_costs") {
+        ctx->row_costs = static_cast<int>(value) != 0;
     } else if (n == "stage_timing") {
         ctx->stage_timing = static_cast<int>(value) != 0;
     } else if (n == "walk_timing") {

@@ -63,7 +63,8 @@ struct RotationList {
 struct ImageParams {
     int32_t res_x, res_y;     // full image
     int32_t n_local_rows;     // rows rendered by this context
-    int32_t tile_rows, rank, world;  // row tile t belongs to rank t % world
+    int32_t tile_rows, rank, world;  // row tile t (counted from row_begin) belongs to rank t % world
+    int32_t row_begin, row_count;    // only rows [row_begin, row_begin + row_count) are rendered at all
     double x_min, y_min;      // bounds[1], bounds[3]
     double step_x, step_y;    // plane.cpp:298-302
 };
@@ -87,14 +88,16 @@ struct FrameCounters {
 
 // global row -> local row of this rank, or -1
 __host__ __device__ inline int local_row_of(const ImageParams& im, int row) {
-    const int tile = row / im.tile_rows;
+    const int r = row - im.row_begin;
+    if (r < 0 || r >= im.row_count) return -1;
+    const int tile = r / im.tile_rows;
     if (tile % im.world != im.rank) return -1;
-    return (tile / im.world) * im.tile_rows + (row - tile * im.tile_rows);
+    return (tile / im.world) * im.tile_rows + (r - tile * im.tile_rows);
 }
 // local row -> global row
 __host__ __device__ inline int global_row_of(const ImageParams& im, int lrow) {
     const int ltile = lrow / im.tile_rows;
-    return (ltile * im.world + im.rank) * im.tile_rows + (lrow - ltile * im.tile_rows);
+    return im.row_begin + (ltile * im.world + im.rank) * im.tile_rows + (lrow - ltile * im.tile_rows);
 }
 
 }  // namespace c5

@@ -20,6 +20,8 @@ struct GridView {  // device pointers of the persistent grid + per-view buffers
     const uint32_t* bface = nullptr;
     CellRecord* rec = nullptr;
     CellOptics* opt = nullptr;
+    // only cells whose projected y-extent meets [cull_y_lo, cull_y_hi] can be reached by a ray of this context
+    double cull_y_lo = 0, cull_y_hi = 0;
 };
 
 struct WalkParams {
@@ -36,8 +38,10 @@ struct WalkParams {
     double t_cutoff;            // front-to-back early-out on transmittance
     uint32_t max_steps;
     int32_t xcd_mode;
+    int32_t band_tiles;         // xcd_mode 1: workgroup-tile rows per band (set by launch_walk)
     int32_t order;              // 0: back to front in the reference's arithmetic; 1: front to back + early-out
     FrameCounters* counters;
+    uint32_t* row_cost;         // [n_local_rows] segments per row of this frame, or nullptr
 };
 
 // exact_kernels.hip (-ffp-contract=off)

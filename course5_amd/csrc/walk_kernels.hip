@@ -32,14 +32,20 @@ __global__ __launch_bounds__(256) void build_records(GridView g, double alpha_li
     const int64_t cell = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
     if (cell >= g.n_cells) return;
     const int4 cv = g.cell_vert[cell];
-    const int4 adj = g.cell_adj[cell];
     const int vid[4] = {cv.x, cv.y, cv.z, cv.w};
-    const int nb[4] = {adj.x, adj.y, adj.z, adj.w};
     double p[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p[k][1] = g.vy[vid[k]];
+    // A ray of this context can only reach cells whose y-extent meets the band of its rows: skip the
+    // rest (their records are never read).  This is what shards the per-view setup across ranks.
+    const double cy_lo = fmin(fmin(p[0][1], p[1][1]), fmin(p[2][1], p[3][1]));
+    const double cy_hi = fmax(fmax(p[0][1], p[1][1]), fmax(p[2][1], p[3][1]));
+    if (cy_hi < g.cull_y_lo || cy_lo > g.cull_y_hi) return;
+    const int4 adj = g.cell_adj[cell];
+    const int nb[4] = {adj.x, adj.y, adj.z, adj.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         p[k][0] = g.vx[vid[k]];
-        p[k][1] = g.vy[vid[k]];
         p[k][2] = g.vz[vid[k]];
     }
     CellRecord r;
@@ -116,6 +122,11 @@ __global__ __launch_bounds__(256) void entry_raster(GridView g, const double* __
     const uint32_t cell = bf >> 2;
     const int f = static_cast<int>(bf & 3u);
     const CellRecord* rec = g.rec + cell;
+    {   // same band test as build_records: a culled cell has no record
+        const int4 cv0 = g.cell_vert[cell];
+        const double y0 = g.vy[cv0.x], y1 = g.vy[cv0.y], y2 = g.vy[cv0.z], y3 = g.vy[cv0.w];
+        if (fmax(fmax(y0, y1), fmax(y2, y3)) < g.cull_y_lo || fmin(fmin(y0, y1), fmin(y2, y3)) > g.cull_y_hi) return;
+    }
     const uint32_t w = rec->nbr[f];
     // walking from +z to -z a ray enters through faces the cell body lies below (upper faces);
     // walking from -z to +z through the others
@@ -140,8 +151,9 @@ __global__ __launch_bounds__(256) void entry_raster(GridView g, const double* __
     if (!(fc1 >= 0.0) || !(fr1 >= 0.0) || !(fc0 <= im.res_x - 1.0) || !(fr0 <= im.res_y - 1.0)) return;
     const int c0 = static_cast<int>(fmax(fc0, 0.0));
     const int c1 = static_cast<int>(fmin(fc1, im.res_x - 1.0));
-    const int r0 = static_cast<int>(fmax(fr0, 0.0));
-    const int r1 = static_cast<int>(fmin(fr1, im.res_y - 1.0));
+    const int r0 = max(static_cast<int>(fmax(fr0, 0.0)), im.row_begin);
+    const int r1 = min(static_cast<int>(fmin(fr1, im.res_y - 1.0)), im.row_begin + im.row_count - 1);
+    if (r1 < r0) return;
     const int bw = c1 - c0 + 1;
     const int64_t n_box = static_cast<int64_t>(bw) * (r1 - r0 + 1);
 
@@ -340,6 +352,49 @@ __device__ __forceinline__ double reference_emission_step(double I, double alpha
 //          (wavefront-uniform skip of the exp work once every lane's T fell below the cut-off).
 //          Algebraically identical; differs from ORDER 0 by rounding only where the reference's
 //          recurrence is itself well conditioned.
+//
+// Structure of a step (one cell of one ray): the record of the current cell is already in
+// registers; the four face planes give the exit face and therefore the next cell; the loads of
+// the NEXT cell's record are issued right there, and the exp/divide work of the CURRENT cell runs
+// while they are in flight.  Face selection is branch-free (selects), so a step has two
+// data-dependent branches only: "this cell contributes" and "the ray left the grid".
+struct CellRegs {
+    D2 r0, r1, r2, r3, r4, r5, r6, r7;  // CellRecord
+    D2 o0, o1;                          // CellOptics
+};
+
+__device__ __forceinline__ void load_cell(CellRegs& c, const CellRecord* rec, const CellOptics* opt, int cell) {
+    const D2* rp = reinterpret_cast<const D2*>(rec + cell);
+    const D2* op = reinterpret_cast<const D2*>(opt + cell);
+    c.r0 = rp[0];
+    c.r1 = rp[1];
+    c.r2 = rp[2];
+    c.r3 = rp[3];
+    c.r4 = rp[4];
+    c.r5 = rp[5];
+    c.r6 = rp[6];
+    c.r7 = rp[7];
+    c.o0 = op[0];
+    c.o1 = op[1];
+}
+
+// next place the ray enters the grid beyond s_cur (s = z walking down, -z walking up); -1 if none
+template <bool kUp>
+__device__ __forceinline__ int next_entry(const Entry* __restrict__ entries, int e0, int e1, double& s_cur) {
+    double s_best = -DBL_MAX;
+    int cell = -1;
+    for (int e = e0; e < e1; ++e) {
+        const Entry en = entries[e];
+        const double se = kUp ? -en.z : en.z;
+        if (se < s_cur && se > s_best) {
+            s_best = se;
+            cell = en.cell;
+        }
+    }
+    if (cell >= 0) s_cur = s_best;
+    return cell;
+}
+
 template <int TILE, int ORDER>
 __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
     using TS = TileShape<TILE>;
@@ -354,10 +409,10 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
         ty = blockIdx.x / tiles_x;
         tx = blockIdx.x - ty * tiles_x;
     } else {
-        // Bands of ~32 image rows are dealt round-robin to the 8 XCDs (blocks b and b + 8 share an
+        // Bands of up to 32 image rows are dealt round-robin to the 8 XCDs (blocks b and b + 8 share an
         // XCD's L2): every XCD sweeps the image top to bottom, so load stays balanced, while the
         // workgroups resident on one XCD at a time cover a compact region of the grid.
-        constexpr int BAND = (32 / TH) > 0 ? (32 / TH) : 1;
+        const int BAND = P.band_tiles;  // tile rows per band (host: ~32 image rows, fewer for short strips)
         const int n_bands = (tiles_y + BAND - 1) / BAND;
         const int per_band = BAND * tiles_x;
         const int xcd = blockIdx.x & 7;
@@ -376,9 +431,11 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
     const bool in_image = (col < im.res_x) && (lrow < im.n_local_rows);
 
     unsigned n_seg = 0, n_step = 0, is_solid = 0, overflow = 0;
-    double tau = 0.0, I = 0.0;
-    float2 result = make_float2(0.f, 0.f);
+    double tau = 0.0, I = 0.0, T = 1.0;
+    double x = 0.0, y = 0.0, s_cur = DBL_MAX;
+    int e0 = 0, e1 = 0, cell = -1;
     size_t lp = 0;
+    float2 result = make_float2(0.f, 0.f);
 
     if (in_image) {
         lp = static_cast<size_t>(lrow) * im.res_x + col;
@@ -392,95 +449,102 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
             result.y = result.x;
             is_solid = 1;
         } else {
-            const double x = P.Xtab[col];
-            const double y = P.Ytab[global_row_of(im, lrow)];
-            const int e0 = P.entry_offs[lp], e1 = P.entry_offs[lp + 1];
-            double T = 1.0;
-            // position along the ray, measured so that it always decreases: s = z walking down, -z walking up
-            double s_cur = DBL_MAX;
-            bool stop = (e1 <= e0);
-            while (!stop) {
-                // next place the ray enters the grid beyond s_cur
-                double s_best = -DBL_MAX;
-                int cell = -1;
-                for (int e = e0; e < e1; ++e) {
-                    const Entry en = P.entries[e];
-                    const double se = kUp ? -en.z : en.z;
-                    if (se < s_cur && se > s_best) {
-                        s_best = se;
-                        cell = en.cell;
-                    }
-                }
-                if (cell < 0) break;
-                s_cur = s_best;
-                while (true) {
-                    const D2* rp = reinterpret_cast<const D2*>(P.rec + cell);
-                    const D2* op = reinterpret_cast<const D2*>(P.opt + cell);
-                    const D2 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4], r5 = rp[5],
-                             r6 = rp[6], r7 = rp[7];
-                    const D2 o0 = op[0], o1 = op[1];
-                    const double dx = x - r0.a, dy = y - r0.b;
-                    // plane k = (c, gx, gy): r1.a r1.b r2.a | r2.b r3.a r3.b | r4.a r4.b r5.a | r5.b r6.a r6.b
-                    const double z0 = fma(r1.b, dx, fma(r2.a, dy, r1.a));
-                    const double z1 = fma(r3.a, dx, fma(r3.b, dy, r2.b));
-                    const double z2 = fma(r4.b, dx, fma(r5.a, dy, r4.a));
-                    const double z3 = fma(r6.a, dx, fma(r6.b, dy, r5.b));
-                    const unsigned long long w01 = __double_as_longlong(r7.a);
-                    const unsigned long long w23 = __double_as_longlong(r7.b);
-                    const uint32_t w0 = static_cast<uint32_t>(w01), w1 = static_cast<uint32_t>(w01 >> 32);
-                    const uint32_t w2 = static_cast<uint32_t>(w23), w3 = static_cast<uint32_t>(w23 >> 32);
-
-                    // the ray is inside the cell between the highest lower face and the lowest upper face
-                    double z_top = DBL_MAX, z_bot = -DBL_MAX;
-                    uint32_t w_top = kNoCell | kFaceSkip, w_bot = kNoCell | kFaceSkip;  // "no such face"
-#define C5_FACE(zk, wk)                                   \
-    if (!((wk)&kFaceSkip)) {                              \
-        if ((wk)&kFaceUpper) {                            \
-            if ((zk) < z_top) {                           \
-                z_top = (zk);                             \
-                w_top = (wk);                             \
-            }                                             \
-        } else if ((zk) > z_bot) {                        \
-            z_bot = (zk);                                 \
-            w_bot = (wk);                                 \
-        }                                                 \
+            x = P.Xtab[col];
+            y = P.Ytab[global_row_of(im, lrow)];
+            e0 = P.entry_offs[lp];
+            e1 = P.entry_offs[lp + 1];
+            if (e1 > e0) cell = next_entry<kUp>(P.entries, e0, e1, s_cur);
+        }
     }
-                    C5_FACE(z0, w0)
-                    C5_FACE(z1, w1)
-                    C5_FACE(z2, w2)
-                    C5_FACE(z3, w3)
-#undef C5_FACE
-                    const double dz = z_top - z_bot;  // line.cpp:124-131
-                    ++n_step;
-                    if (dz > 0.0 && z_top < DBL_MAX && z_bot > -DBL_MAX) {
-                        ++n_seg;
-                        tau = fma(dz, o0.a, tau);  // line.cpp:189 (unclamped alpha)
-                        if (ORDER == 0) {
-                            if (o0.b != 0.0) I = reference_emission_step(I, o0.b, o1.b, dz);  // line.cpp:220-224 (NaN alpha propagates)
-                        } else if (T >= P.t_cutoff) {
-                            // I = sum_k T_k (Q/alpha)(1 - e^{-alpha dz}); T_{k+1} = T_k e^{-alpha dz}
-                            const double ex = exp(-o0.b * dz);
-                            I = fma(T * o1.a, 1.0 - ex, I);
-                            T *= ex;
-                        }
-                    }
-                    const uint32_t w_out = kUp ? w_top : w_bot;
-                    if (w_out & kFaceSkip) break;  // no exit face: flat cell, give up on this span
-                    s_cur = fmin(s_cur, kUp ? -z_top : z_bot);
-                    const uint32_t nb = w_out & kIdMask;
-                    if (nb == kNoCell) break;  // left the grid; look for a re-entry
-                    cell = static_cast<int>(nb);
-                    if (n_step >= P.max_steps) {
-                        overflow = 1;
-                        stop = true;
-                        break;
-                    }
-                }
+
+    CellRegs cur;
+    if (cell >= 0) load_cell(cur, P.rec, P.opt, cell);
+
+    while (cell >= 0) {
+        const double dx = x - cur.r0.a, dy = y - cur.r0.b;
+        // plane k = (c, gx, gy): r1.a r1.b r2.a | r2.b r3.a r3.b | r4.a r4.b r5.a | r5.b r6.a r6.b
+        const double z0 = fma(cur.r1.b, dx, fma(cur.r2.a, dy, cur.r1.a));
+        const double z1 = fma(cur.r3.a, dx, fma(cur.r3.b, dy, cur.r2.b));
+        const double z2 = fma(cur.r4.b, dx, fma(cur.r5.a, dy, cur.r4.a));
+        const double z3 = fma(cur.r6.a, dx, fma(cur.r6.b, dy, cur.r5.b));
+        const unsigned long long w01 = __double_as_longlong(cur.r7.a);
+        const unsigned long long w23 = __double_as_longlong(cur.r7.b);
+        const uint32_t w0 = static_cast<uint32_t>(w01), w1 = static_cast<uint32_t>(w01 >> 32);
+        const uint32_t w2 = static_cast<uint32_t>(w23), w3 = static_cast<uint32_t>(w23 >> 32);
+
+        // The ray is inside the cell between the highest lower face and the lowest upper face:
+        // those are the two faces the reference pairs for this (pixel, tet) (line.cpp:99-131).
+        constexpr uint32_t kKind = kFaceUpper | kFaceSkip;
+        const double u0 = (w0 & kKind) == kFaceUpper ? z0 : DBL_MAX, l0 = (w0 & kKind) == 0u ? z0 : -DBL_MAX;
+        const double u1 = (w1 & kKind) == kFaceUpper ? z1 : DBL_MAX, l1 = (w1 & kKind) == 0u ? z1 : -DBL_MAX;
+        const double u2 = (w2 & kKind) == kFaceUpper ? z2 : DBL_MAX, l2 = (w2 & kKind) == 0u ? z2 : -DBL_MAX;
+        const double u3 = (w3 & kKind) == kFaceUpper ? z3 : DBL_MAX, l3 = (w3 & kKind) == 0u ? z3 : -DBL_MAX;
+        const double z_top = fmin(fmin(u0, u1), fmin(u2, u3));
+        const double z_bot = fmax(fmax(l0, l1), fmax(l2, l3));
+        // exit face = the one that realised the extremum (first in face order on ties)
+        uint32_t w_out;
+        bool has_exit;
+        if (kUp) {
+            w_out = (u0 == z_top) ? w0 : (u1 == z_top) ? w1 : (u2 == z_top) ? w2 : w3;
+            has_exit = z_top < DBL_MAX;
+        } else {
+            w_out = (l0 == z_bot) ? w0 : (l1 == z_bot) ? w1 : (l2 == z_bot) ? w2 : w3;
+            has_exit = z_bot > -DBL_MAX;
+        }
+        const double dz = z_top - z_bot;  // line.cpp:124-131
+        const bool contributes = dz > 0.0 && z_top < DBL_MAX && z_bot > -DBL_MAX;
+        ++n_step;
+
+        // where next?
+        int nb = -1;
+        if (has_exit) {
+            s_cur = fmin(s_cur, kUp ? -z_top : z_bot);
+            const uint32_t id = w_out & kIdMask;
+            if (id != kNoCell) nb = static_cast<int>(id);
+        }
+        if (nb >= 0 && n_step >= P.max_steps) {  // malformed grid: never spin
+            overflow = 1;
+            nb = -1;
+        } else if (nb < 0 && !overflow) {
+            nb = next_entry<kUp>(P.entries, e0, e1, s_cur);  // left the grid: re-entry of a non-convex grid?
+        }
+
+        // issue the next cell's loads now; the arithmetic below does not depend on them
+        CellRegs nxt;
+        if (nb >= 0) load_cell(nxt, P.rec, P.opt, nb);
+
+        if (contributes) {
+            ++n_seg;
+            tau = fma(dz, cur.o0.a, tau);  // line.cpp:189 (unclamped alpha)
+            if (ORDER == 0) {
+                // line.cpp:220-224 (NaN alpha propagates like there)
+                if (cur.o0.b != 0.0) I = reference_emission_step(I, cur.o0.b, cur.o1.b, dz);
+            } else if (T >= P.t_cutoff) {
+                // I = sum_k T_k (Q/alpha)(1 - e^{-alpha dz}); T_{k+1} = T_k e^{-alpha dz}
+                const double ex = exp(-cur.o0.b * dz);
+                I = fma(T * cur.o1.a, 1.0 - ex, I);
+                T *= ex;
             }
+        }
+        cell = nb;
+        cur = nxt;
+    }
+
+    if (in_image) {
+        if (!is_solid) {
             result.x = static_cast<float>(tau);  // plane.cpp:165
             result.y = static_cast<float>(I);    // plane.cpp:166
         }
         P.out[lp] = result;
+    }
+
+    // segments per image row (load balancing of row blocks across GPUs): reduce over the lanes of a
+    // wavefront that share a row (WW consecutive lanes), one atomic per row and wavefront
+    if (P.row_cost) {
+        unsigned rs = n_seg;
+#pragma unroll
+        for (int d = TS::WW / 2; d >= 1; d >>= 1) rs += __shfl_xor(rs, d);
+        if ((lane % TS::WW) == 0 && rs && lrow < im.n_local_rows) atomicAdd(P.row_cost + lrow, rs);
     }
 
     // per-wavefront statistics -> one atomic each
@@ -509,10 +573,16 @@ static void launch_walk_t(hipStream_t s, const WalkParams& p) {
     if (p.xcd_mode == 0) {
         blocks = static_cast<long long>(tiles_x) * tiles_y;
     } else {
-        constexpr int BAND = (32 / TH) > 0 ? (32 / TH) : 1;
-        const int n_bands = (tiles_y + BAND - 1) / BAND;
+        // ~32 image rows per band, but never fewer than 16 bands (2 per XCD) on a short strip
+        int band = (32 / TH) > 0 ? (32 / TH) : 1;
+        while (band > 1 && (tiles_y + band - 1) / band < 16) band >>= 1;
+        const int n_bands = (tiles_y + band - 1) / band;
         const int rounds = (n_bands + 7) / 8;
-        blocks = 8ll * rounds * BAND * tiles_x;
+        blocks = 8ll * rounds * band * tiles_x;
+        WalkParams q = p;
+        q.band_tiles = band;
+        hipLaunchKernelGGL((walk_composite<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, q);
+        return;
     }
     hipLaunchKernelGGL((walk_composite<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
 }

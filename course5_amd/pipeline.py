@@ -1,12 +1,20 @@
-"""Frame pipeline of the multi-GPU path: each rank renders its row tiles, one gather of the
-strips to rank 0 per frame (RCCL on the GPU box; gloo in the CPU tests), reassembly there.
+"""Frame pipeline of the multi-GPU path: each rank renders its rows, one gather of the strips to
+rank 0 per frame (RCCL on the GPU box; gloo in the CPU tests), reassembly there.
 
 The reference has no exchange step (one process, plane.cpp:161-169 loops over all pixels); the
 gather exists only because the image plane is sharded.  Up to `depth` gathers stay in flight so
 the exchange of frame k overlaps the render of frame k + 1.
+
+Two row layouts:
+  cyclic  tiles of `tile_rows` rows dealt round-robin (c5_set_row_tiles): balanced by
+          construction, but every rank touches the whole grid, so the per-view setup is replicated;
+  blocks  one contiguous block per rank (c5_set_row_range), sized by measured per-row cost
+          (sharding.balanced_blocks): each rank builds only the records its rays can reach, which
+          shards the per-view setup as well.
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -14,11 +22,18 @@ from . import sharding
 
 
 class FramePipeline:
-    def __init__(self, res_x: int, res_y: int, tile_rows: int, rank: int, world: int, device, depth: int = 2):
+    def __init__(self, res_x: int, res_y: int, rank: int, world: int, device, depth: int = 2,
+                 tile_rows: int = 16, blocks=None):
         self.res_x, self.res_y, self.tile_rows = res_x, res_y, tile_rows
         self.rank, self.world, self.device = rank, world, device
+        self.blocks = list(blocks) if blocks is not None else None
         self.depth = max(1, depth) if world > 1 else 1
-        self.pad_rows = sharding.padded_rows(res_y, tile_rows, world) if world > 1 else res_y
+        if world == 1:
+            self.pad_rows = res_y
+        elif self.blocks is not None:
+            self.pad_rows = max(n for _, n in self.blocks)
+        else:
+            self.pad_rows = sharding.padded_rows(res_y, tile_rows, world)
         self.strips = [torch.zeros((self.pad_rows, res_x, 2), dtype=torch.float32, device=device)
                        for _ in range(self.depth)]
         self.frame = None
@@ -27,8 +42,9 @@ class FramePipeline:
         if world > 1 and rank == 0:
             self.parts = [[torch.empty_like(self.strips[0]) for _ in range(world)] for _ in range(self.depth)]
             self.frame = torch.empty((res_y, res_x, 2), dtype=torch.float32, device=device)
-            self.row_index = [torch.from_numpy(sharding.local_rows(res_y, tile_rows, r, world)).to(device)
-                              for r in range(world)]
+            if self.blocks is None:
+                self.row_index = [torch.from_numpy(sharding.local_rows(res_y, tile_rows, r, world)).to(device)
+                                  for r in range(world)]
         self.pending = []
         self.k = 0
 
@@ -37,8 +53,12 @@ class FramePipeline:
         work.wait()  # on GPU: the current stream waits for the collective, the host does not
         if self.rank == 0:
             for r in range(self.world):
-                idx = self.row_index[r]
-                self.frame.index_copy_(0, idx, self.parts[s][r][: idx.numel()])
+                if self.blocks is not None:
+                    b, n = self.blocks[r]
+                    self.frame[b:b + n].copy_(self.parts[s][r][:n])
+                else:
+                    idx = self.row_index[r]
+                    self.frame.index_copy_(0, idx, self.parts[s][r][: idx.numel()])
 
     def step(self, render):
         """render(strip) must fill strip[:local_rows] (enqueue on the current stream on GPU)."""
@@ -57,3 +77,19 @@ class FramePipeline:
         while self.pending:
             self._finish(self.pending.pop(0))
         return self.frame
+
+
+def gather_row_costs(local_costs: np.ndarray, blocks, rank: int, world: int, device) -> np.ndarray:
+    """All ranks: per-row costs of the whole image from each rank's block (one small all_gather)."""
+    res_y = sum(n for _, n in blocks)
+    if world == 1:
+        return np.asarray(local_costs, dtype=np.int64)
+    pad = max(n for _, n in blocks)
+    mine = torch.zeros(pad, dtype=torch.int64, device=device)
+    mine[: len(local_costs)] = torch.from_numpy(np.asarray(local_costs, dtype=np.int64)).to(device)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    out = np.zeros(res_y, dtype=np.int64)
+    for (b, n), p in zip(blocks, parts):
+        out[b:b + n] = p[:n].cpu().numpy()
+    return out

@@ -33,3 +33,47 @@ def assemble(strips, res_y: int, tile_rows: int, world: int) -> np.ndarray:
         rows = local_rows(res_y, tile_rows, r, world)
         out[rows] = np.asarray(strips[r])[: rows.size]
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# contiguous, cost-balanced row blocks (one block per rank)
+# ---------------------------------------------------------------------------------------------
+def equal_blocks(res_y: int, world: int):
+    """[(begin, count)] per rank: res_y rows split as evenly as possible."""
+    edges = [(r * res_y) // world for r in range(world + 1)]
+    return [(edges[r], edges[r + 1] - edges[r]) for r in range(world)]
+
+
+def balanced_blocks(row_costs, world: int, base_cost: float = 0.0, min_rows: int = 1):
+    """Split rows into `world` contiguous blocks of (nearly) equal total cost.
+
+    row_costs[r] = measured cost of row r (segments of the previous frame); base_cost is added per
+    row for the work every pixel costs regardless (entry lookup, store).  Every block gets at least
+    min_rows rows.  Deterministic, so every rank computes the same partition from the same costs.
+    """
+    c = np.asarray(row_costs, dtype=np.float64) + float(base_cost)
+    res_y = c.size
+    if res_y < world * min_rows:
+        raise ValueError("more ranks than rows")
+    cum = np.concatenate([[0.0], np.cumsum(c)])
+    total = cum[-1]
+    edges = [0]
+    for r in range(1, world):
+        target = total * r / world
+        e = int(np.searchsorted(cum, target, side="left"))
+        # nearest of the two candidate cut positions
+        if e > 0 and abs(cum[e - 1] - target) <= abs(cum[min(e, res_y)] - target):
+            e -= 1
+        e = max(e, edges[-1] + min_rows)
+        e = min(e, res_y - (world - r) * min_rows)
+        edges.append(e)
+    edges.append(res_y)
+    return [(edges[r], edges[r + 1] - edges[r]) for r in range(world)]
+
+
+def assemble_blocks(strips, blocks, res_y: int) -> np.ndarray:
+    res_x = strips[0].shape[1]
+    out = np.empty((res_y, res_x, 2), dtype=strips[0].dtype)
+    for s, (b, n) in zip(strips, blocks):
+        out[b:b + n] = np.asarray(s)[:n]
+    return out

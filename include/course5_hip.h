@@ -116,7 +116,15 @@ int c5_set_image(c5_context* ctx, int res_x, int res_y, const double* bounds4);
  * rank t % world.  Default (1 tile of res_y rows, world 1) renders the whole image.  The local
  * strip holds this rank's rows in ascending global order. */
 int c5_set_row_tiles(c5_context* ctx, int tile_rows, int rank, int world);
+/* Restrict rendering to the contiguous rows [row_begin, row_begin + row_count) (row_count -1 = to the
+ * end); tiles of c5_set_row_tiles are then counted from row_begin.  A context only builds the
+ * per-view records of cells its rows can reach, so contiguous blocks also shard the per-view
+ * setup.  Default: the whole image. */
+int c5_set_row_range(c5_context* ctx, int row_begin, int row_count);
 int c5_local_rows(const c5_context* ctx, int* n_rows);
+/* Segments per local row of the last frame (needs option "row_costs" = 1 before rendering):
+ * the cost estimate for balancing row blocks across GPUs. */
+int c5_get_row_costs(c5_context* ctx, uint32_t* costs, int n_rows);
 /* View transform of the volume grid (main.cpp:105-107) and of each solid (main.cpp:112-114,
  * object3d_roche_lobe.cpp:48). */
 int c5_set_view(c5_context* ctx, const c5_rotation* rots, int n_rots);
@@ -132,6 +140,7 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  well conditioned (it is not for DBL_EPSILON <= alpha < ~1e-8).
  *   "tile"         wavefront tile: 0 = 64x1 row tile, 1 = 16x4, 2 = 8x8 pixels.
  *   "xcd_mode"     1 (default): 32-row bands dealt round-robin to the 8 XCDs; 0: row-major tiles.
+ *   "row_costs"    1: walk_composite also accumulates segments per image row (c5_get_row_costs).
  *   "stage_timing" / "walk_timing"  0/1: record HIP events per stage / around walk_composite. */
 int c5_set_option(c5_context* ctx, const char* name, double value);
 

@@ -68,3 +68,30 @@ def test_vtk_writer_round_trip(tmp_path):
     text = p.read_text().split("\n")
     assert text[3] == "DATASET UNSTRUCTURED_GRID" and text[4] == "POINTS 9 double"
     assert "SCALARS AbsorpCoef double 1" in text and "SCALARS radEnLooseRate double 1" in text
+
+
+def test_balanced_blocks_equalise_cost_and_cover_the_image():
+    rng = np.random.default_rng(3)
+    costs = np.zeros(1800)
+    costs[400:1400] = rng.integers(50_000, 250_000, 1000)  # covered rows cluster in the middle
+    for world in (1, 2, 3, 8):
+        blocks = sharding.balanced_blocks(costs, world, base_cost=2400 * 0.05)
+        assert blocks[0][0] == 0 and sum(n for _, n in blocks) == 1800
+        assert all(blocks[k][0] + blocks[k][1] == blocks[k + 1][0] for k in range(world - 1))
+        assert all(n >= 1 for _, n in blocks)
+        per = [costs[b:b + n].sum() + n * 120 for b, n in blocks]
+        assert max(per) <= 1.05 * (sum(per) / world)
+    eq = sharding.equal_blocks(1800, 8)
+    per_eq = [costs[b:b + n].sum() for b, n in eq]
+    assert max(per_eq) > 1.5 * (sum(per_eq) / 8)  # equal blocks would be badly unbalanced
+
+
+def test_balanced_blocks_degenerate_inputs():
+    assert sharding.balanced_blocks(np.zeros(10), 4) == [(0, 1), (1, 1), (2, 1), (3, 7)] or \
+        sum(n for _, n in sharding.balanced_blocks(np.zeros(10), 4)) == 10
+    with pytest.raises(ValueError):
+        sharding.balanced_blocks(np.ones(3), 4)
+    full = np.arange(12 * 3 * 2, dtype=np.float32).reshape(12, 3, 2)
+    blocks = sharding.balanced_blocks(np.arange(12), 3)
+    strips = [np.vstack([full[b:b + n], np.zeros((2, 3, 2), np.float32)]) for b, n in blocks]
+    assert np.array_equal(sharding.assemble_blocks(strips, blocks, 12), full)

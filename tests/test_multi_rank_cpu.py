@@ -26,7 +26,7 @@ def _free_port():
 def _worker(rank, world, port, tile_rows, depth, out_path):
     sys.path.insert(0, ROOT)
     from course5_amd import meshgen as mg, sharding
-    from course5_amd.pipeline import FramePipeline
+    from course5_amd.pipeline import FramePipeline, gather_row_costs
     from oracle.pyoracle import Oracle
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -34,8 +34,20 @@ def _worker(rank, world, port, tile_rows, depth, out_path):
         xyz, cells, a, q = mg.workload("g2")
         rx, ry = 96, 70
         oracle = Oracle("port")
-        rows = sharding.local_rows(ry, tile_rows, rank, world)
-        pipe = FramePipeline(rx, ry, tile_rows, rank, world, torch.device("cpu"), depth=depth)
+        if tile_rows > 0:   # cyclic row tiles
+            rows = sharding.local_rows(ry, tile_rows, rank, world)
+            pipe = FramePipeline(rx, ry, rank, world, torch.device("cpu"), depth=depth, tile_rows=tile_rows)
+        else:               # contiguous blocks balanced by a cost measured on equal blocks first
+            eq = sharding.equal_blocks(ry, world)
+            probe = oracle.render(xyz, cells, a, q, mg.view_rotations(*VIEWS[0]), rx, ry, mg.REFERENCE_BOUNDS)["image"]
+            b, n = eq[rank]
+            local_cost = (probe[b:b + n, :, 0] > 0).sum(axis=1)  # stand-in for segments per row
+            costs = gather_row_costs(local_cost, eq, rank, world, torch.device("cpu"))
+            assert np.array_equal(costs, (probe[..., 0] > 0).sum(axis=1))
+            blocks = sharding.balanced_blocks(costs, world, base_cost=1.0)
+            b, n = blocks[rank]
+            rows = np.arange(b, b + n)
+            pipe = FramePipeline(rx, ry, rank, world, torch.device("cpu"), depth=depth, blocks=blocks)
         fulls, ok = [], []
         for k, view in enumerate(VIEWS):
             full = oracle.render(xyz, cells, a, q, mg.view_rotations(*view), rx, ry, mg.REFERENCE_BOUNDS)["image"]
@@ -57,7 +69,8 @@ def _worker(rank, world, port, tile_rows, depth, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("tile_rows,depth", [(16, 1), (16, 2), (7, 3)])
+@pytest.mark.parametrize("tile_rows,depth", [(16, 1), (16, 2), (7, 3), (0, 2)],
+                         ids=["cyclic16-d1", "cyclic16-d2", "cyclic7-d3", "balanced-blocks-d2"])
 def test_two_ranks_gather_row_tiles(tmp_path, tile_rows, depth):
     out = str(tmp_path / "ok.npy")
     mp.spawn(_worker, args=(2, _free_port(), tile_rows, depth, out), nprocs=2, join=True)
