@@ -52,6 +52,7 @@ def parse():
                    help="N > 1: weak = per-GPU rays stay at --res (image grows by sqrt(N) per side; N = 4 is "
                         "BASELINE config 4, 4800x3600); strong = the same --res frame split over N GPUs")
     p.add_argument("--tile", type=int, default=-1, help="wavefront tile shape override (0: 64x1, 1: 16x4, 2: 8x8)")
+    p.add_argument("--lds-stage", type=int, default=-1, help="override: 1 = LDS-staged walk kernel, 0 = direct loads")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-res", default="1200x900")
     p.add_argument("--pipeline-depth", type=int, default=2, help="N > 1: frames whose gather may be in flight")
@@ -127,6 +128,8 @@ def main():
     ctx.set_option("stage_timing", 0)
     if args.tile >= 0:
         ctx.set_option("tile", args.tile)
+    if args.lds_stage >= 0:
+        ctx.set_option("lds_stage", args.lds_stage)
     ctx.set_stream(stream.cuda_stream)
 
     def render(strip):

@@ -88,6 +88,7 @@ struct c5_context {
     int tile_shape = 0;
     int xcd_mode = 1;
     int order = 0;
+    int lds_stage = 1;
     int stage_timing = 1;
     int walk_timing = 1;
 
@@ -298,6 +299,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     wp.max_steps = static_cast<uint32_t>(ctx->n_cells + 64);
     wp.xcd_mode = ctx->xcd_mode;
     wp.order = ctx->order;
+    wp.lds_stage = ctx->lds_stage;
     wp.counters = ctx->counters.as<c5::FrameCounters>();
     wp.row_cost = nullptr;
     if (ctx->row_costs && im.n_local_rows > 0) {
@@ -678,6 +680,8 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
         ctx->tile_shape = static_cast<int>(value);
     } else if (n == "transmittance_cutoff") {
         ctx->t_cutoff = value;
+    } else if (n == "lds_stage") {
+        ctx->lds_stage = static_cast<int>(value) != 0;
     } else if (n == "integration") {
         ctx->order = static_cast<int>(value) != 0;
     } else if (n == "xcd_mode") {

@@ -562,6 +562,253 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// walk_composite_lds: the same walk with the current cells staged through LDS.
+//
+// Neighbouring pixels of a row tile are mostly inside the same cell, so per step a wavefront
+// needs only a handful of distinct 160-byte records, not 64.  The direct kernel still issues
+// ten 16-byte loads per lane and step and is bound by the CU's vector-memory address path
+// (rocprofv3: 2.9e7 VMEM wave-instructions per frame).  Here the wavefront
+//   1. finds the runs of equal next-cell ids along its lanes (compare with the lane to the left,
+//      ballot, popcount -> slot per run),
+//   2. loads each run's record ONCE, cooperatively: 8 lanes x 16 B per CellRecord, 2 lanes x 16 B
+//      per CellOptics (coalesced 128-byte and 32-byte segments),
+//   3. parks the pieces in a wave-private LDS area (144-byte stride: conflict-free b128 reads),
+//   4. and every lane reads its own cell's record from LDS (lanes of a run broadcast).
+// The global loads of step k+1 are issued as soon as the exit face of step k is known and are in
+// flight during step k's exp/divide work, as in the direct kernel.
+// ------------------------------------------------------------------------------------------
+constexpr int kStageSlots = 24;   // runs of equal cell ids staged per wavefront and step (more: direct loads)
+constexpr int kRecStride = 9;     // CellRecord stride in LDS, 16-byte units (128 B + 16 B pad)
+using V2 = double __attribute__((ext_vector_type(2)));  // 16 bytes as one SSA value (never an alloca)
+__device__ __forceinline__ D2 as_d2(V2 v) { return D2{v.x, v.y}; }
+
+template <int TILE, int ORDER>
+__global__ __launch_bounds__(256) void walk_composite_lds(WalkParams P) {
+    using TS = TileShape<TILE>;
+    constexpr int TW = TS::WW * TS::GX, TH = TS::WH * TS::GY;
+    constexpr bool kUp = (ORDER == 0);
+    __shared__ V2 s_rec[4][kStageSlots * kRecStride];
+    __shared__ V2 s_opt[4][kStageSlots * 2];
+
+    const ImageParams& im = P.im;
+    const int tiles_x = (im.res_x + TW - 1) / TW;
+    const int tiles_y = (im.n_local_rows + TH - 1) / TH;
+    int tx, ty;
+    if (P.xcd_mode == 0) {
+        ty = blockIdx.x / tiles_x;
+        tx = blockIdx.x - ty * tiles_x;
+    } else {
+        const int BAND = P.band_tiles;
+        const int n_bands = (tiles_y + BAND - 1) / BAND;
+        const int per_band = BAND * tiles_x;
+        const int xcd = blockIdx.x & 7;
+        const int seq = blockIdx.x >> 3;
+        const int band = (seq / per_band) * 8 + xcd;
+        const int within = seq - (seq / per_band) * per_band;
+        if (band >= n_bands) return;
+        ty = band * BAND + within % BAND;
+        tx = within / BAND;
+        if (ty >= tiles_y) return;
+    }
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = tx * TW + (wave % TS::GX) * TS::WW + (lane % TS::WW);
+    const int lrow = ty * TH + (wave / TS::GX) * TS::WH + (lane / TS::WW);
+    const bool in_image = (col < im.res_x) && (lrow < im.n_local_rows);
+    V2* const my_rec = s_rec[wave];
+    V2* const my_opt = s_opt[wave];
+    const unsigned long long lanes_le = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+
+    unsigned n_seg = 0, n_step = 0, is_solid = 0, overflow = 0;
+    double tau = 0.0, I = 0.0, T = 1.0;
+    double x = 0.0, y = 0.0, s_cur = DBL_MAX;
+    int e0 = 0, e1 = 0, nb = -1;
+    size_t lp = 0;
+    float2 result = make_float2(0.f, 0.f);
+
+    if (in_image) {
+        lp = static_cast<size_t>(lrow) * im.res_x + col;
+        const uint32_t mv = P.mask ? P.mask[lp] : 0u;
+        if (mv) {
+            double colour = 0.0;
+            for (int s = 0; s < P.solids.n_slots; ++s)
+                if (mv > P.solids.first_id[s] && mv <= P.solids.first_id[s + 1]) colour = P.solids.colour[s];
+            result.x = static_cast<float>(colour);
+            result.y = result.x;
+            is_solid = 1;
+        } else {
+            x = P.Xtab[col];
+            y = P.Ytab[global_row_of(im, lrow)];
+            e0 = P.entry_offs[lp];
+            e1 = P.entry_offs[lp + 1];
+            if (e1 > e0) nb = next_entry<kUp>(P.entries, e0, e1, s_cur);
+        }
+    }
+
+    // contribution of the step whose record is being replaced (integrated while the next loads fly)
+    bool pend = false;
+    double pend_dz = 0.0, pend_a_raw = 0.0, pend_a = 0.0, pend_s = 0.0;
+
+    while (true) {  // wave-uniform: every lane helps with the staging until all rays are done
+        const bool need = nb >= 0;
+        if (__ballot(need) == 0ull) break;
+
+        // 1. runs of equal cell ids -> slots
+        const int left = __shfl_up(nb, 1);
+        const bool head = need && (lane == 0 || left != nb);
+        const unsigned long long heads = __ballot(head);
+        const int n_runs = __popcll(heads);
+        const int slot = __popcll(heads & lanes_le) - 1;  // valid where need
+        const int n_staged = n_runs < kStageSlots ? n_runs : kStageSlots;
+        // lane s learns the cell id of slot s (forward permute from the run heads)
+        const int id_of_lane = __builtin_amdgcn_ds_permute((head ? slot : 63) << 2, head ? nb : -1);
+        // 2. cooperative loads into registers: record pieces (8 lanes per slot, 8 slots per pass)
+        // Three passes of 8 slots (8 lanes x 16 B per record) + one pass for the optics (2 lanes per
+        // slot).  Lanes beyond the staged slots re-load slot 0's piece (same cache line, free) so that
+        // the loads are unconditional and the values stay in registers.  (40 slots with conditional
+        // passes measured slower: 1.52 vs 1.32 ms on the C3 frame.)
+        static_assert(kStageSlots == 24, "three record passes are written out below");
+        const int piece = lane & 7, sub = lane >> 3, so = lane >> 1;
+        const int id0 = __builtin_amdgcn_ds_bpermute((sub < n_staged ? sub : 0) << 2, id_of_lane);
+        const int id1 = __builtin_amdgcn_ds_bpermute((sub + 8 < n_staged ? sub + 8 : 0) << 2, id_of_lane);
+        const int id2 = __builtin_amdgcn_ds_bpermute((sub + 16 < n_staged ? sub + 16 : 0) << 2, id_of_lane);
+        const int ido = __builtin_amdgcn_ds_bpermute((so < n_staged ? so : 0) << 2, id_of_lane);
+        const V2 stage_r0 = reinterpret_cast<const V2*>(P.rec + id0)[piece];
+        const V2 stage_r1 = reinterpret_cast<const V2*>(P.rec + id1)[piece];
+        const V2 stage_r2 = reinterpret_cast<const V2*>(P.rec + id2)[piece];
+        const V2 stage_o0 = reinterpret_cast<const V2*>(P.opt + ido)[lane & 1];
+
+        // ... while they are in flight: emission/absorption of the step just taken
+        if (pend) {
+            ++n_seg;
+            tau = fma(pend_dz, pend_a_raw, tau);  // line.cpp:189
+            if (ORDER == 0) {
+                if (pend_a != 0.0) I = reference_emission_step(I, pend_a, pend_s, pend_dz);  // line.cpp:220-224
+            } else if (T >= P.t_cutoff) {
+                const double ex = exp(-pend_a * pend_dz);
+                I = fma(T * pend_s, 1.0 - ex, I);
+                T *= ex;
+            }
+            pend = false;
+        }
+
+        // 3. park the pieces in LDS (the previous step's reads are long done: same wavefront, in order)
+        __builtin_amdgcn_wave_barrier();
+        if (sub < n_staged) my_rec[sub * kRecStride + piece] = stage_r0;
+        if (sub + 8 < n_staged) my_rec[(sub + 8) * kRecStride + piece] = stage_r1;
+        if (sub + 16 < n_staged) my_rec[(sub + 16) * kRecStride + piece] = stage_r2;
+        if (so < n_staged) my_opt[lane] = stage_o0;
+        __builtin_amdgcn_wave_barrier();
+
+        // 4. every ray fetches its cell
+        CellRegs cur;
+        if (need) {
+            if (slot < kStageSlots) {
+                const V2* r = my_rec + slot * kRecStride;
+                cur.r0 = as_d2(r[0]);
+                cur.r1 = as_d2(r[1]);
+                cur.r2 = as_d2(r[2]);
+                cur.r3 = as_d2(r[3]);
+                cur.r4 = as_d2(r[4]);
+                cur.r5 = as_d2(r[5]);
+                cur.r6 = as_d2(r[6]);
+                cur.r7 = as_d2(r[7]);
+                cur.o0 = as_d2(my_opt[slot * 2]);
+                cur.o1 = as_d2(my_opt[slot * 2 + 1]);
+            } else {
+                load_cell(cur, P.rec, P.opt, nb);  // more distinct cells than slots: rare
+            }
+
+            const double dx = x - cur.r0.a, dy = y - cur.r0.b;
+            const double z0 = fma(cur.r1.b, dx, fma(cur.r2.a, dy, cur.r1.a));
+            const double z1 = fma(cur.r3.a, dx, fma(cur.r3.b, dy, cur.r2.b));
+            const double z2 = fma(cur.r4.b, dx, fma(cur.r5.a, dy, cur.r4.a));
+            const double z3 = fma(cur.r6.a, dx, fma(cur.r6.b, dy, cur.r5.b));
+            const unsigned long long w01 = __double_as_longlong(cur.r7.a);
+            const unsigned long long w23 = __double_as_longlong(cur.r7.b);
+            const uint32_t w0 = static_cast<uint32_t>(w01), w1 = static_cast<uint32_t>(w01 >> 32);
+            const uint32_t w2 = static_cast<uint32_t>(w23), w3 = static_cast<uint32_t>(w23 >> 32);
+            constexpr uint32_t kKind = kFaceUpper | kFaceSkip;
+            const double u0 = (w0 & kKind) == kFaceUpper ? z0 : DBL_MAX, l0 = (w0 & kKind) == 0u ? z0 : -DBL_MAX;
+            const double u1 = (w1 & kKind) == kFaceUpper ? z1 : DBL_MAX, l1 = (w1 & kKind) == 0u ? z1 : -DBL_MAX;
+            const double u2 = (w2 & kKind) == kFaceUpper ? z2 : DBL_MAX, l2 = (w2 & kKind) == 0u ? z2 : -DBL_MAX;
+            const double u3 = (w3 & kKind) == kFaceUpper ? z3 : DBL_MAX, l3 = (w3 & kKind) == 0u ? z3 : -DBL_MAX;
+            const double z_top = fmin(fmin(u0, u1), fmin(u2, u3));
+            const double z_bot = fmax(fmax(l0, l1), fmax(l2, l3));
+            uint32_t w_out;
+            bool has_exit;
+            if (kUp) {
+                w_out = (u0 == z_top) ? w0 : (u1 == z_top) ? w1 : (u2 == z_top) ? w2 : w3;
+                has_exit = z_top < DBL_MAX;
+            } else {
+                w_out = (l0 == z_bot) ? w0 : (l1 == z_bot) ? w1 : (l2 == z_bot) ? w2 : w3;
+                has_exit = z_bot > -DBL_MAX;
+            }
+            const double dz = z_top - z_bot;  // line.cpp:124-131
+            ++n_step;
+            if (dz > 0.0 && z_top < DBL_MAX && z_bot > -DBL_MAX) {
+                pend = true;
+                pend_dz = dz;
+                pend_a_raw = cur.o0.a;
+                pend_a = cur.o0.b;
+                pend_s = (ORDER == 0) ? cur.o1.b : cur.o1.a;  // Q for the reference recurrence, Q/alpha otherwise
+            }
+            int nxt = -1;
+            if (has_exit) {
+                s_cur = fmin(s_cur, kUp ? -z_top : z_bot);
+                const uint32_t id = w_out & kIdMask;
+                if (id != kNoCell) nxt = static_cast<int>(id);
+            }
+            if (nxt >= 0 && n_step >= P.max_steps) {
+                overflow = 1;
+                nxt = -1;
+            } else if (nxt < 0 && !overflow) {
+                nxt = next_entry<kUp>(P.entries, e0, e1, s_cur);
+            }
+            nb = nxt;
+        }
+    }
+    if (pend) {  // the last step's contribution
+        ++n_seg;
+        tau = fma(pend_dz, pend_a_raw, tau);
+        if (ORDER == 0) {
+            if (pend_a != 0.0) I = reference_emission_step(I, pend_a, pend_s, pend_dz);
+        } else if (T >= P.t_cutoff) {
+            const double ex = exp(-pend_a * pend_dz);
+            I = fma(T * pend_s, 1.0 - ex, I);
+            T *= ex;
+        }
+    }
+
+    if (in_image) {
+        if (!is_solid) {
+            result.x = static_cast<float>(tau);  // plane.cpp:165
+            result.y = static_cast<float>(I);    // plane.cpp:166
+        }
+        P.out[lp] = result;
+    }
+
+    if (P.row_cost) {
+        unsigned rs = n_seg;
+#pragma unroll
+        for (int d = TS::WW / 2; d >= 1; d >>= 1) rs += __shfl_xor(rs, d);
+        if ((lane % TS::WW) == 0 && rs && lrow < im.n_local_rows) atomicAdd(P.row_cost + lrow, rs);
+    }
+    const unsigned s_seg = wave_sum_u32(n_seg);
+    const unsigned s_step = wave_sum_u32(n_step);
+    const unsigned s_cov = wave_sum_u32(n_seg > 0 ? 1u : 0u);
+    const unsigned s_sol = wave_sum_u32(is_solid);
+    const unsigned s_ovf = wave_sum_u32(overflow);
+    if (lane == 0) {
+        if (s_seg) atomicAdd(&P.counters->segments, static_cast<unsigned long long>(s_seg));
+        if (s_step) atomicAdd(&P.counters->steps, static_cast<unsigned long long>(s_step));
+        if (s_cov) atomicAdd(&P.counters->covered, static_cast<unsigned long long>(s_cov));
+        if (s_sol) atomicAdd(&P.counters->solid_pixels, static_cast<unsigned long long>(s_sol));
+        if (s_ovf) atomicAdd(&P.counters->walk_overflow, s_ovf);
+    }
+}
+
 template <int TILE, int ORDER>
 static void launch_walk_t(hipStream_t s, const WalkParams& p) {
     using TS = TileShape<TILE>;
@@ -581,10 +828,16 @@ static void launch_walk_t(hipStream_t s, const WalkParams& p) {
         blocks = 8ll * rounds * band * tiles_x;
         WalkParams q = p;
         q.band_tiles = band;
-        hipLaunchKernelGGL((walk_composite<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, q);
+        if (p.lds_stage)
+            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, q);
+        else
+            hipLaunchKernelGGL((walk_composite<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, q);
         return;
     }
-    hipLaunchKernelGGL((walk_composite<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+    if (p.lds_stage)
+        hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((walk_composite<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
 }
 
 void launch_walk(hipStream_t s, const WalkParams& p, int tile_shape) {

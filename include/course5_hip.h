@@ -138,6 +138,8 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  once the transmittance T falls below "transmittance_cutoff" (default 1e-12,
  *                  0 disables).  Both agree to rounding wherever the reference's recurrence is
  *                  well conditioned (it is not for DBL_EPSILON <= alpha < ~1e-8).
+ *   "lds_stage"    1 (default): walk_composite_lds — per step a wavefront loads each distinct cell
+ *                  record once and stages it through LDS; 0: every lane loads its own record.
  *   "tile"         wavefront tile: 0 = 64x1 row tile, 1 = 16x4, 2 = 8x8 pixels.
  *   "xcd_mode"     1 (default): 32-row bands dealt round-robin to the 8 XCDs; 0: row-major tiles.
  *   "row_costs"    1: walk_composite also accumulates segments per image row (c5_get_row_costs).

@@ -9,16 +9,17 @@ ctx.upload_grid(xyz, c, a, q)
 res = (2400, 1800) if len(sys.argv) < 3 else tuple(int(v) for v in sys.argv[2].split("x"))
 ctx.set_image(res[0], res[1], mg.REFERENCE_BOUNDS)
 ctx.set_view(mg.view_rotations(0.1, 0.07))
-for order in (0, 1):
-    for tile in (0, 1, 2):
-        for xm in (1, 0):
-            ctx.set_option("integration", order); ctx.set_option("tile", tile); ctx.set_option("xcd_mode", xm)
+import itertools
+for lds, order, tile, xm in itertools.product((0, 1), (0, 1), (0, 1, 2), (1,)):
+    if True:
+        if True:
+            ctx.set_option("lds_stage", lds); ctx.set_option("integration", order); ctx.set_option("tile", tile); ctx.set_option("xcd_mode", xm)
             best = None
             for i in range(8):
                 ctx.render()
                 st = ctx.stats()
                 if best is None or st["ms_walk"] < best["ms_walk"]:
                     best = st
-            print("order", order, "tile", tile, "xcd", xm, "walk", round(best["ms_walk"], 3), "total", round(best["ms_total"], 3),
+            print("lds", lds, "order", order, "tile", tile, "xcd", xm, "walk", round(best["ms_walk"], 3), "total", round(best["ms_total"], 3),
                   "tr/rec/ent", round(best["ms_transform"], 3), round(best["ms_records"], 3), round(best["ms_entries"], 3),
                   "S", best["segments"], flush=True)
