@@ -53,6 +53,9 @@ def parse():
                         "BASELINE config 4, 4800x3600); strong = the same --res frame split over N GPUs")
     p.add_argument("--tile", type=int, default=-1, help="wavefront tile shape override (0: 64x1, 1: 16x4, 2: 8x8)")
     p.add_argument("--lds-stage", type=int, default=-1, help="override: 1 = LDS-staged walk kernel, 0 = direct loads")
+    p.add_argument("--pipeline", type=int, default=-1, help="override: overlap the next frame's setup with the walk (1) or not (0)")
+    p.add_argument("--own-stream", action="store_true", help="run on the context's own (high priority) stream")
+    p.add_argument("--backend", default="nccl", help="nccl (= RCCL, default); gloo only to rehearse N > 1 on one GPU")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-res", default="1200x900")
     p.add_argument("--pipeline-depth", type=int, default=2, help="N > 1: frames whose gather may be in flight")
@@ -106,11 +109,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if os.environ.get("C5_BENCH_ONE_DEVICE"):  # rehearsal only: every rank on GPU 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     res_x, res_y = (int(v) for v in args.res.lower().split("x"))
     base_res = (res_x, res_y)
@@ -121,6 +129,8 @@ def main():
 
     stream = torch.cuda.Stream(device=dev)
     ctx = capi.Context(local_rank)
+    if args.pipeline >= 0:
+        ctx.set_option("pipeline", args.pipeline)
     ctx.upload_grid(xyz, cells, alpha, q)
     ctx.set_image(res_x, res_y, mg.REFERENCE_BOUNDS)
     ctx.set_view(rots)
@@ -130,7 +140,8 @@ def main():
         ctx.set_option("tile", args.tile)
     if args.lds_stage >= 0:
         ctx.set_option("lds_stage", args.lds_stage)
-    ctx.set_stream(stream.cuda_stream)
+    if not args.own_stream:
+        ctx.set_stream(stream.cuda_stream)
 
     def render(strip):
         ctx.render_device(strip.data_ptr())
@@ -149,13 +160,14 @@ def main():
             render(probe)
             while ctx.synchronize() == capi.C5_RETRY:
                 render(probe)
-            costs = gather_row_costs(ctx.row_costs(), eq, rank, world, dev)
+            costs = gather_row_costs(ctx.row_costs(), eq, rank, world, dev if args.backend == "nccl" else torch.device("cpu"))
             blocks = sharding.balanced_blocks(costs, world, base_cost=res_x * args.row_base_cost)
             ctx.set_option("row_costs", 0)
             ctx.set_row_range(*blocks[rank])
             del probe
     n_local = ctx.local_rows
-    pipe = FramePipeline(res_x, res_y, rank, world, dev, depth=args.pipeline_depth, tile_rows=TILE_ROWS, blocks=blocks)
+    pipe = FramePipeline(res_x, res_y, rank, world, dev, depth=args.pipeline_depth, tile_rows=TILE_ROWS, blocks=blocks,
+                         host_staging=args.backend != "nccl")
 
     with torch.cuda.stream(stream):
         # warm-up (also lets the entry buffer reach its size: C5_RETRY means "render again")
@@ -186,9 +198,10 @@ def main():
             raise SystemExit("frame had to be re-rendered inside the timed region; run with more warmup")
         walk_ms, walk_launches = ctx.walk_kernel_ms(reset=True)
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    seg = torch.tensor([stats["segments"], n_local * res_x], dtype=torch.int64, device=dev)
-    wk = torch.tensor([walk_ms], dtype=torch.float64, device=dev)
+    rdev = dev if args.backend == "nccl" else torch.device("cpu")
+    el = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
+    seg = torch.tensor([stats["segments"], n_local * res_x], dtype=torch.int64, device=rdev)
+    wk = torch.tensor([walk_ms], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(seg, op=dist.ReduceOp.SUM)

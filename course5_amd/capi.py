@@ -2,6 +2,10 @@
 
 Test/bench plumbing only: the product is the shared library and the `course` CLI.  There is no
 CPU fallback here — if the library is missing or no GPU is present, calls raise.
+
+When device buffers are shared with PyTorch (render_device into a torch tensor), import torch
+BEFORE the first call into this module: torch bundles its own HIP runtime, and whichever runtime is
+loaded first serves the whole process.
 """
 from __future__ import annotations
 

@@ -50,11 +50,25 @@ struct DeviceBuffer {
 struct Solid {
     int64_t n_tets = 0;
     double colour = 0.0;
-    DeviceBuffer raw, view;  // [n][4][3] doubles
+    DeviceBuffer raw;        // [n][4][3] doubles, as given
+    DeviceBuffer view[2];    // transformed copy, one per frame slot
     c5::RotationList rots{};
 };
 
 constexpr int kWalkEventPool = 512;
+constexpr int kFrameSlots = 2;
+
+// Everything one frame writes before its image: two slots, so that the per-view setup of frame
+// k + 1 (HBM-bound: transform, records, entry lists, solid mask) can run on the auxiliary stream
+// while walk_composite of frame k (VALU / address-path bound) runs on the main stream.
+struct FrameSlot {
+    DeviceBuffer vx, vy, vz, rec, opt, count, offs, scratch, entries, mask, counters, row_cost;
+    int64_t entry_capacity = 0;
+    c5::FrameCounters* host_counters = nullptr;  // pinned
+    hipEvent_t setup_done = nullptr, walk_done = nullptr;
+    bool walk_recorded = false;
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
 
 }  // namespace
 
@@ -66,7 +80,12 @@ struct c5_context {
 
     // persistent grid
     int64_t n_pts = 0, n_cells = 0, n_bfaces = 0;
-    DeviceBuffer px, py, pz, vx, vy, vz, cell_vert, cell_adj, alpha, q, bface, rec, opt;
+    hipStream_t aux_stream = nullptr;  // per-view setup of the next frame
+    DeviceBuffer px, py, pz, cell_vert, cell_adj, alpha, q, bface;
+    FrameSlot slots[kFrameSlots];
+    int64_t frame_index = 0;
+    int last_slot = 0;
+    int pipeline = 0;  // measured: overlapping the next setup with the walk is slower (1.43 vs 1.38 ms/frame)
     c5::RotationList view{};
     Solid solids[C5_MAX_SOLIDS];
 
@@ -76,11 +95,9 @@ struct c5_context {
     c5::ImageParams im{};
     int cfg_tile_rows = 0, cfg_rank = 0, cfg_world = 1;
     int cfg_row_begin = 0, cfg_row_count = -1;  // -1: all rows
-    DeviceBuffer xtab, ytab, count, offs, scratch, entries, mask, out, counters, row_cost;
+    DeviceBuffer xtab, ytab, out;
     std::vector<double> host_ytab;
     int row_costs = 0;
-    int64_t entry_capacity = 0;
-    c5::FrameCounters* host_counters = nullptr;  // pinned
 
     // options
     double alpha_limit = 2.5;
@@ -93,7 +110,6 @@ struct c5_context {
     int walk_timing = 1;
 
     // events
-    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t walk_a[kWalkEventPool];
     hipEvent_t walk_b[kWalkEventPool];
     int walk_used = 0;
@@ -171,20 +187,32 @@ int ensure_image_buffers(c5_context* ctx) {
     const c5::ImageParams& im = ctx->im;
     const int64_t n_px = static_cast<int64_t>(im.n_local_rows) * im.res_x;
     const int64_t padded = ((n_px + 1023) / 1024) * 1024;
-    C5_HIP(ctx, ctx->count.ensure(static_cast<size_t>(padded + 1024) * sizeof(int32_t)));
-    C5_HIP(ctx, ctx->offs.ensure(static_cast<size_t>(padded + 1024) * sizeof(int32_t)));
-    C5_HIP(ctx, ctx->scratch.ensure(static_cast<size_t>(padded / 1024 + 1024) * sizeof(int32_t)));
-    C5_HIP(ctx, ctx->mask.ensure(static_cast<size_t>(padded) * sizeof(uint32_t)));
     C5_HIP(ctx, ctx->out.ensure(static_cast<size_t>(padded) * sizeof(float) * 2));
-    C5_HIP(ctx, ctx->row_cost.ensure(static_cast<size_t>(im.n_local_rows + 64) * sizeof(uint32_t)));
-    if (ctx->entry_capacity < 2 * n_px + 1024) {
-        ctx->entry_capacity = 2 * n_px + 1024;
-        C5_HIP(ctx, ctx->entries.ensure(static_cast<size_t>(ctx->entry_capacity) * sizeof(c5::Entry)));
+    for (int k = 0; k < (ctx->pipeline ? kFrameSlots : 1); ++k) {
+        FrameSlot& fs = ctx->slots[k];
+        C5_HIP(ctx, fs.count.ensure(static_cast<size_t>(padded + 1024) * sizeof(int32_t)));
+        C5_HIP(ctx, fs.offs.ensure(static_cast<size_t>(padded + 1024) * sizeof(int32_t)));
+        C5_HIP(ctx, fs.scratch.ensure(static_cast<size_t>(padded / 1024 + 1024) * sizeof(int32_t)));
+        C5_HIP(ctx, fs.mask.ensure(static_cast<size_t>(padded) * sizeof(uint32_t)));
+        C5_HIP(ctx, fs.row_cost.ensure(static_cast<size_t>(im.n_local_rows + 64) * sizeof(uint32_t)));
+        if (fs.entry_capacity < 2 * n_px + 1024) {
+            fs.entry_capacity = 2 * n_px + 1024;
+            C5_HIP(ctx, fs.entries.ensure(static_cast<size_t>(fs.entry_capacity) * sizeof(c5::Entry)));
+        }
     }
     return C5_OK;
 }
 
-// Enqueue one frame on the context's stream; the image goes to out_dev.
+// Wait until nothing of this context is running (both streams).
+int drain(c5_context* ctx) {
+    C5_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->aux_stream) C5_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
+    return C5_OK;
+}
+
+// Enqueue one frame; the image goes to out_dev.  The per-view setup runs on the auxiliary stream
+// into frame slot (frame_index & 1), the walk on the main stream once that setup is done, so the
+// setup of the next frame overlaps this frame's walk.
 int enqueue_frame(c5_context* ctx, float2* out_dev) {
     if (ctx->n_cells <= 0 && [&] {
             for (const Solid& s : ctx->solids)
@@ -195,18 +223,22 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     if (!ctx->have_image) return fail(ctx, C5_ERR_STATE, "critical error. empty plane");  // plane.cpp:151-153
     int rc = bind_device(ctx);
     if (rc) return rc;
-    rc = ensure_image_buffers(ctx);
-    if (rc) return rc;
 
-    hipStream_t s = ctx->stream;
+    const int slot_id = ctx->pipeline ? static_cast<int>(ctx->frame_index & 1) : 0;
+    FrameSlot& fs = ctx->slots[slot_id];
+    hipStream_t main_s = ctx->stream;
+    hipStream_t s = ctx->pipeline ? ctx->aux_stream : ctx->stream;  // setup stream
     const c5::ImageParams& im = ctx->im;
     const int64_t n_px = static_cast<int64_t>(im.n_local_rows) * im.res_x;
     const int64_t padded = ((n_px + 1023) / 1024) * 1024;
     const bool timed = ctx->stage_timing != 0;
-    auto mark = [&](int k) -> hipError_t { return timed ? hipEventRecord(ctx->ev[k], s) : hipSuccess; };
+    auto mark = [&](int k, hipStream_t st) -> hipError_t { return timed ? hipEventRecord(fs.ev[k], st) : hipSuccess; };
 
-    C5_HIP(ctx, mark(0));
-    C5_HIP(ctx, hipMemsetAsync(ctx->counters.ptr, 0, sizeof(c5::FrameCounters), s));
+    // the slot's buffers are free once the walk that last read them has finished
+    if (ctx->pipeline && fs.walk_recorded) C5_HIP(ctx, hipStreamWaitEvent(s, fs.walk_done, 0));
+
+    C5_HIP(ctx, mark(0, s));
+    C5_HIP(ctx, hipMemsetAsync(fs.counters.ptr, 0, sizeof(c5::FrameCounters), s));
 
     c5::GridView g;
     g.n_pts = ctx->n_pts;
@@ -215,16 +247,16 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     g.px = ctx->px.as<double>();
     g.py = ctx->py.as<double>();
     g.pz = ctx->pz.as<double>();
-    g.vx = ctx->vx.as<double>();
-    g.vy = ctx->vy.as<double>();
-    g.vz = ctx->vz.as<double>();
+    g.vx = fs.vx.as<double>();
+    g.vy = fs.vy.as<double>();
+    g.vz = fs.vz.as<double>();
     g.cell_vert = ctx->cell_vert.as<int4>();
     g.cell_adj = ctx->cell_adj.as<int4>();
     g.alpha = ctx->alpha.as<double>();
     g.q = ctx->q.as<double>();
     g.bface = ctx->bface.as<uint32_t>();
-    g.rec = ctx->rec.as<c5::CellRecord>();
-    g.opt = ctx->opt.as<c5::CellOptics>();
+    g.rec = fs.rec.as<c5::CellRecord>();
+    g.opt = fs.opt.as<c5::CellOptics>();
     // y band of the rows this context renders (one pixel of slack on both sides)
     if (im.n_local_rows > 0) {
         const int first = c5::global_row_of(im, 0), last = c5::global_row_of(im, im.n_local_rows - 1);
@@ -239,24 +271,24 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
 
     // (a2) view transform
     c5::launch_transform_soa(s, g.px, g.py, g.pz, g.vx, g.vy, g.vz, g.n_pts, ctx->view);
-    C5_HIP(ctx, mark(1));
+    C5_HIP(ctx, mark(1, s));
     // (a1, a10, a13 constants) per-cell records
     c5::launch_build_records(s, g, ctx->alpha_limit);
-    C5_HIP(ctx, mark(2));
+    C5_HIP(ctx, mark(2, s));
     // boundary entries: count -> scan -> fill
-    C5_HIP(ctx, hipMemsetAsync(ctx->count.ptr, 0, static_cast<size_t>(padded + 1) * sizeof(int32_t), s));
+    C5_HIP(ctx, hipMemsetAsync(fs.count.ptr, 0, static_cast<size_t>(padded + 1) * sizeof(int32_t), s));
     if (g.n_cells > 0) {
-        c5::launch_entry_count(s, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im, ctx->count.as<int32_t>(),
+        c5::launch_entry_count(s, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im, fs.count.as<int32_t>(),
                                 ctx->order != 0);
     }
-    c5::launch_exclusive_scan(s, ctx->count.as<int32_t>(), ctx->offs.as<int32_t>(), n_px,
-                              ctx->scratch.as<int32_t>(), ctx->counters.as<c5::FrameCounters>());
+    c5::launch_exclusive_scan(s, fs.count.as<int32_t>(), fs.offs.as<int32_t>(), n_px, fs.scratch.as<int32_t>(),
+                              fs.counters.as<c5::FrameCounters>());
     if (g.n_cells > 0) {
-        c5::launch_entry_fill(s, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im, ctx->count.as<int32_t>(),
-                              ctx->offs.as<int32_t>(), ctx->entries.as<c5::Entry>(), ctx->entry_capacity,
-                              ctx->counters.as<c5::FrameCounters>(), ctx->order != 0);
+        c5::launch_entry_fill(s, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im, fs.count.as<int32_t>(),
+                              fs.offs.as<int32_t>(), fs.entries.as<c5::Entry>(), fs.entry_capacity,
+                              fs.counters.as<c5::FrameCounters>(), ctx->order != 0);
     }
-    C5_HIP(ctx, mark(3));
+    C5_HIP(ctx, mark(3, s));
     // (a9) solids
     c5::SolidTable table{};
     bool any_solid = false;
@@ -272,24 +304,24 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     table.first_id[C5_MAX_SOLIDS] = next_id;
     table.n_slots = C5_MAX_SOLIDS;
     if (any_solid) {
-        C5_HIP(ctx, hipMemsetAsync(ctx->mask.ptr, 0, static_cast<size_t>(padded) * sizeof(uint32_t), s));
+        C5_HIP(ctx, hipMemsetAsync(fs.mask.ptr, 0, static_cast<size_t>(padded) * sizeof(uint32_t), s));
         for (int k = 0; k < C5_MAX_SOLIDS; ++k) {
             Solid& so = ctx->solids[k];
             if (so.n_tets <= 0) continue;
-            c5::launch_transform_aos(s, so.raw.as<double>(), so.view.as<double>(), 4 * so.n_tets, so.rots);
-            c5::launch_solid_mask_raster(s, so.view.as<double>(), so.n_tets, table.first_id[k],
-                                         ctx->ytab.as<double>(), im, ctx->mask.as<uint32_t>());
+            c5::launch_transform_aos(s, so.raw.as<double>(), so.view[slot_id].as<double>(), 4 * so.n_tets, so.rots);
+            c5::launch_solid_mask_raster(s, so.view[slot_id].as<double>(), so.n_tets, table.first_id[k],
+                                         ctx->ytab.as<double>(), im, fs.mask.as<uint32_t>());
         }
     }
-    C5_HIP(ctx, mark(4));
+    C5_HIP(ctx, mark(4, s));
 
-    // (a11-a14) walk
+    // (a11-a14) walk on the main stream, after this slot's setup
     c5::WalkParams wp{};
     wp.rec = g.rec;
     wp.opt = g.opt;
-    wp.entry_offs = ctx->offs.as<int32_t>();
-    wp.entries = ctx->entries.as<c5::Entry>();
-    wp.mask = any_solid ? ctx->mask.as<uint32_t>() : nullptr;
+    wp.entry_offs = fs.offs.as<int32_t>();
+    wp.entries = fs.entries.as<c5::Entry>();
+    wp.mask = any_solid ? fs.mask.as<uint32_t>() : nullptr;
     wp.solids = table;
     wp.Xtab = ctx->xtab.as<double>();
     wp.Ytab = ctx->ytab.as<double>();
@@ -300,14 +332,18 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     wp.xcd_mode = ctx->xcd_mode;
     wp.order = ctx->order;
     wp.lds_stage = ctx->lds_stage;
-    wp.counters = ctx->counters.as<c5::FrameCounters>();
+    wp.counters = fs.counters.as<c5::FrameCounters>();
     wp.row_cost = nullptr;
     if (ctx->row_costs && im.n_local_rows > 0) {
-        wp.row_cost = ctx->row_cost.as<uint32_t>();
-        C5_HIP(ctx, hipMemsetAsync(ctx->row_cost.ptr, 0, static_cast<size_t>(im.n_local_rows) * sizeof(uint32_t), s));
+        wp.row_cost = fs.row_cost.as<uint32_t>();
+        C5_HIP(ctx, hipMemsetAsync(fs.row_cost.ptr, 0, static_cast<size_t>(im.n_local_rows) * sizeof(uint32_t), s));
+    }
+    if (ctx->pipeline) {
+        C5_HIP(ctx, hipEventRecord(fs.setup_done, s));
+        C5_HIP(ctx, hipStreamWaitEvent(main_s, fs.setup_done, 0));
     }
 
-    int slot = -1;
+    int ev_slot = -1;
     if (ctx->walk_timing) {
         if (ctx->walk_used == kWalkEventPool) {  // fold the pool before reusing it
             for (int k = 0; k < kWalkEventPool; ++k) {
@@ -319,16 +355,20 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
             ctx->walk_launches += kWalkEventPool;
             ctx->walk_used = 0;
         }
-        slot = ctx->walk_used++;
-        C5_HIP(ctx, hipEventRecord(ctx->walk_a[slot], s));
+        ev_slot = ctx->walk_used++;
+        C5_HIP(ctx, hipEventRecord(ctx->walk_a[ev_slot], main_s));
     }
-    c5::launch_walk(s, wp, ctx->tile_shape);
-    if (slot >= 0) C5_HIP(ctx, hipEventRecord(ctx->walk_b[slot], s));
-    C5_HIP(ctx, mark(5));
+    c5::launch_walk(main_s, wp, ctx->tile_shape);
+    if (ev_slot >= 0) C5_HIP(ctx, hipEventRecord(ctx->walk_b[ev_slot], main_s));
+    C5_HIP(ctx, mark(5, main_s));
     C5_HIP(ctx, hipGetLastError());
-
-    C5_HIP(ctx, hipMemcpyAsync(ctx->host_counters, ctx->counters.ptr, sizeof(c5::FrameCounters),
-                               hipMemcpyDeviceToHost, s));
+    C5_HIP(ctx, hipMemcpyAsync(fs.host_counters, fs.counters.ptr, sizeof(c5::FrameCounters), hipMemcpyDeviceToHost, main_s));
+    if (ctx->pipeline) {
+        C5_HIP(ctx, hipEventRecord(fs.walk_done, main_s));
+        fs.walk_recorded = true;
+    }
+    ctx->last_slot = slot_id;
+    ctx->frame_index += 1;
     ctx->frame_pending = true;
     ctx->frame_timed = timed;
     return C5_OK;
@@ -338,7 +378,8 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
 int finish_frame(c5_context* ctx) {
     if (!ctx->frame_pending) return C5_OK;
     ctx->frame_pending = false;
-    const c5::FrameCounters& hc = *ctx->host_counters;
+    FrameSlot& fs = ctx->slots[ctx->last_slot];
+    const c5::FrameCounters& hc = *fs.host_counters;
     c5_stats& st = ctx->last;
     st.segments = static_cast<int64_t>(hc.segments);
     st.covered_pixels = static_cast<int64_t>(hc.covered);
@@ -349,15 +390,21 @@ int finish_frame(c5_context* ctx) {
     st.walk_overflow = static_cast<int32_t>(hc.walk_overflow);
     if (ctx->frame_timed) {
         float* dst[5] = {&st.ms_transform, &st.ms_records, &st.ms_entries, &st.ms_solids, &st.ms_walk};
-        for (int k = 0; k < 5; ++k) C5_HIP(ctx, hipEventElapsedTime(dst[k], ctx->ev[k], ctx->ev[k + 1]));
-        C5_HIP(ctx, hipEventElapsedTime(&st.ms_total, ctx->ev[0], ctx->ev[5]));
+        for (int k = 0; k < 5; ++k) C5_HIP(ctx, hipEventElapsedTime(dst[k], fs.ev[k], fs.ev[k + 1]));
+        C5_HIP(ctx, hipEventElapsedTime(&st.ms_total, fs.ev[0], fs.ev[5]));
     }
-    if (hc.entry_overflow || static_cast<int64_t>(hc.entries) > ctx->entry_capacity) {
+    if (hc.entry_overflow || static_cast<int64_t>(hc.entries) > fs.entry_capacity) {
         st.entry_overflow += 1;
-        ctx->entry_capacity = static_cast<int64_t>(hc.entries) + static_cast<int64_t>(hc.entries) / 4 + 1024;
-        C5_HIP(ctx, ctx->entries.ensure(static_cast<size_t>(ctx->entry_capacity) * sizeof(c5::Entry)));
+        const int64_t want = static_cast<int64_t>(hc.entries) + static_cast<int64_t>(hc.entries) / 4 + 1024;
+        int rc = drain(ctx);
+        if (rc) return rc;
+        for (FrameSlot& o : ctx->slots) {
+            if (o.entry_capacity >= want) continue;
+            o.entry_capacity = want;
+            C5_HIP(ctx, o.entries.ensure(static_cast<size_t>(want) * sizeof(c5::Entry)));
+        }
         return fail(ctx, C5_RETRY, "entry buffer grown to %lld records; render the frame again",
-                    static_cast<long long>(ctx->entry_capacity));
+                    static_cast<long long>(want));
     }
     if (hc.walk_overflow)
         return fail(ctx, C5_ERR_WALK, "%u rays exceeded the walk step bound (malformed grid?)", hc.walk_overflow);
@@ -401,11 +448,30 @@ int c5_create(int device_ordinal, c5_context** out_ctx) {
         return C5_ERR_HIP;
     };
     if ((e = hipSetDevice(device_ordinal)) != hipSuccess) return bail(e, "hipSetDevice");
-    if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess)
-        return bail(e, "hipStreamCreate");
+    {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if ((e = hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, hi)) != hipSuccess)
+            return bail(e, "hipStreamCreate");
+    }
     ctx->stream = ctx->own_stream;
-    for (auto& ev : ctx->ev)
-        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
+    {   // the setup stream only fills what the walk leaves idle: lowest priority
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if ((e = hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, lo)) != hipSuccess)
+            return bail(e, "hipStreamCreate");
+    }
+    for (FrameSlot& fs : ctx->slots) {
+        for (auto& ev : fs.ev)
+            if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
+        if ((e = hipEventCreateWithFlags(&fs.setup_done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+        if ((e = hipEventCreateWithFlags(&fs.walk_done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+        if ((e = fs.counters.ensure(sizeof(c5::FrameCounters))) != hipSuccess) return bail(e, "hipMalloc");
+        if ((e = hipHostMalloc(reinterpret_cast<void**>(&fs.host_counters), sizeof(c5::FrameCounters),
+                               hipHostMallocDefault)) != hipSuccess)
+            return bail(e, "hipHostMalloc");
+        std::memset(fs.host_counters, 0, sizeof(c5::FrameCounters));
+    }
     for (int k = 0; k < kWalkEventPool; ++k) {
         ctx->walk_a[k] = ctx->walk_b[k] = nullptr;
     }
@@ -413,11 +479,6 @@ int c5_create(int device_ordinal, c5_context** out_ctx) {
         if ((e = hipEventCreate(&ctx->walk_a[k])) != hipSuccess) return bail(e, "hipEventCreate");
         if ((e = hipEventCreate(&ctx->walk_b[k])) != hipSuccess) return bail(e, "hipEventCreate");
     }
-    if ((e = ctx->counters.ensure(sizeof(c5::FrameCounters))) != hipSuccess) return bail(e, "hipMalloc");
-    if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->host_counters), sizeof(c5::FrameCounters),
-                           hipHostMallocDefault)) != hipSuccess)
-        return bail(e, "hipHostMalloc");
-    std::memset(ctx->host_counters, 0, sizeof(c5::FrameCounters));
     ctx->view.n = 0;
     for (Solid& s : ctx->solids) s.rots.n = 0;
     *out_ctx = ctx;
@@ -428,23 +489,30 @@ void c5_destroy(c5_context* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DeviceBuffer* bufs[] = {&ctx->px, &ctx->py, &ctx->pz, &ctx->vx, &ctx->vy, &ctx->vz, &ctx->cell_vert,
-                            &ctx->cell_adj, &ctx->alpha, &ctx->q, &ctx->bface, &ctx->rec, &ctx->opt,
-                            &ctx->xtab, &ctx->ytab, &ctx->count, &ctx->offs, &ctx->scratch, &ctx->entries,
-                            &ctx->mask, &ctx->out, &ctx->counters, &ctx->row_cost};
+    if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
+    DeviceBuffer* bufs[] = {&ctx->px, &ctx->py, &ctx->pz, &ctx->cell_vert, &ctx->cell_adj, &ctx->alpha,
+                            &ctx->q, &ctx->bface, &ctx->xtab, &ctx->ytab, &ctx->out};
     for (DeviceBuffer* b : bufs) b->release();
-    for (Solid& s : ctx->solids) {
-        s.raw.release();
-        s.view.release();
+    for (FrameSlot& fs : ctx->slots) {
+        DeviceBuffer* sb[] = {&fs.vx, &fs.vy, &fs.vz, &fs.rec, &fs.opt, &fs.count, &fs.offs, &fs.scratch,
+                              &fs.entries, &fs.mask, &fs.counters, &fs.row_cost};
+        for (DeviceBuffer* b : sb) b->release();
+        if (fs.host_counters) (void)hipHostFree(fs.host_counters);
+        for (auto& ev : fs.ev)
+            if (ev) (void)hipEventDestroy(ev);
+        if (fs.setup_done) (void)hipEventDestroy(fs.setup_done);
+        if (fs.walk_done) (void)hipEventDestroy(fs.walk_done);
     }
-    if (ctx->host_counters) (void)hipHostFree(ctx->host_counters);
-    for (auto& ev : ctx->ev)
-        if (ev) (void)hipEventDestroy(ev);
+    for (Solid& so : ctx->solids) {
+        so.raw.release();
+        for (DeviceBuffer& v : so.view) v.release();
+    }
     for (int k = 0; k < kWalkEventPool; ++k) {
         if (ctx->walk_a[k]) (void)hipEventDestroy(ctx->walk_a[k]);
         if (ctx->walk_b[k]) (void)hipEventDestroy(ctx->walk_b[k]);
     }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     delete ctx;
 }
 
@@ -488,19 +556,25 @@ int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int3
     const size_t pb = static_cast<size_t>(n_pts) * sizeof(double);
     const size_t cb = static_cast<size_t>(n_cells);
     C5_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    DeviceBuffer* pbufs[] = {&ctx->px, &ctx->py, &ctx->pz, &ctx->vx, &ctx->vy, &ctx->vz};
+    DeviceBuffer* pbufs[] = {&ctx->px, &ctx->py, &ctx->pz};
     for (DeviceBuffer* b : pbufs) C5_HIP(ctx, b->ensure(pb ? pb : 8));
+    for (int k = 0; k < (ctx->pipeline ? kFrameSlots : 1); ++k) {
+        FrameSlot& fs = ctx->slots[k];
+        C5_HIP(ctx, fs.vx.ensure(pb ? pb : 8));
+        C5_HIP(ctx, fs.vy.ensure(pb ? pb : 8));
+        C5_HIP(ctx, fs.vz.ensure(pb ? pb : 8));
+        C5_HIP(ctx, fs.rec.ensure(cb * sizeof(c5::CellRecord) + 128));
+        C5_HIP(ctx, fs.opt.ensure(cb * sizeof(c5::CellOptics) + 32));
+        // records of cells outside a context's row band are never rebuilt; keep whatever they hold a
+        // valid record (neighbour ids inside the grid) from the start
+        C5_HIP(ctx, hipMemset(fs.rec.ptr, 0, fs.rec.bytes));
+        C5_HIP(ctx, hipMemset(fs.opt.ptr, 0, fs.opt.bytes));
+    }
     C5_HIP(ctx, ctx->cell_vert.ensure(cb * 16 + 16));
     C5_HIP(ctx, ctx->cell_adj.ensure(cb * 16 + 16));
     C5_HIP(ctx, ctx->alpha.ensure(cb * 8 + 8));
     C5_HIP(ctx, ctx->q.ensure(cb * 8 + 8));
     C5_HIP(ctx, ctx->bface.ensure(bfaces.size() * 4 + 4));
-    C5_HIP(ctx, ctx->rec.ensure(cb * sizeof(c5::CellRecord) + 128));
-    C5_HIP(ctx, ctx->opt.ensure(cb * sizeof(c5::CellOptics) + 32));
-    // records of cells outside a context's row band are never rebuilt; keep whatever they hold a
-    // valid record (neighbour ids inside the grid) from the start
-    C5_HIP(ctx, hipMemset(ctx->rec.ptr, 0, ctx->rec.bytes));
-    C5_HIP(ctx, hipMemset(ctx->opt.ptr, 0, ctx->opt.bytes));
     if (n_pts > 0) {
         C5_HIP(ctx, hipMemcpy(ctx->px.ptr, sx.data(), pb, hipMemcpyHostToDevice));
         C5_HIP(ctx, hipMemcpy(ctx->py.ptr, sy.data(), pb, hipMemcpyHostToDevice));
@@ -552,7 +626,7 @@ int c5_set_solid(c5_context* ctx, int slot, const double* tets, int64_t n_tets, 
     if (n_tets > 0) {
         const size_t bytes = static_cast<size_t>(n_tets) * 12 * sizeof(double);
         C5_HIP(ctx, s.raw.ensure(bytes));
-        C5_HIP(ctx, s.view.ensure(bytes));
+        for (int k = 0; k < (ctx->pipeline ? kFrameSlots : 1); ++k) C5_HIP(ctx, s.view[k].ensure(bytes));
         C5_HIP(ctx, hipMemcpy(s.raw.ptr, tets, bytes, hipMemcpyHostToDevice));
     }
     return C5_OK;
@@ -564,7 +638,8 @@ int c5_set_image(c5_context* ctx, int res_x, int res_y, const double* bounds4) {
     if (res_x < 2 || res_y < 2) return fail(ctx, C5_ERR_INVALID, "critical error. empty plane");
     int rc = bind_device(ctx);
     if (rc) return rc;
-    C5_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rc = drain(ctx);
+    if (rc) return rc;
     std::memcpy(ctx->bounds, bounds4, sizeof ctx->bounds);
     c5::ImageParams& im = ctx->im;
     im.res_x = res_x;
@@ -645,7 +720,7 @@ int c5_get_row_costs(c5_context* ctx, uint32_t* costs, int n_rows) {
     int rc = c5_synchronize(ctx);
     if (rc) return rc;
     if (n_rows > 0)
-        C5_HIP(ctx, hipMemcpy(costs, ctx->row_cost.ptr, static_cast<size_t>(n_rows) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        C5_HIP(ctx, hipMemcpy(costs, ctx->slots[ctx->last_slot].row_cost.ptr, static_cast<size_t>(n_rows) * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return C5_OK;
 }
 
@@ -680,6 +755,14 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
         ctx->tile_shape = static_cast<int>(value);
     } else if (n == "transmittance_cutoff") {
         ctx->t_cutoff = value;
+    } else if (n == "pipeline") {
+        int rc = bind_device(ctx);
+        if (rc) return rc;
+        rc = drain(ctx);
+        if (rc) return rc;
+        if (ctx->n_cells > 0 || ctx->have_image)
+            return fail(ctx, C5_ERR_STATE, "set \"pipeline\" before uploading the grid and setting the image");
+        ctx->pipeline = static_cast<int>(value) != 0;
     } else if (n == "lds_stage") {
         ctx->lds_stage = static_cast<int>(value) != 0;
     } else if (n == "integration") {
@@ -777,9 +860,9 @@ int c5_download_view_points(c5_context* ctx, double* xyz) {
     const size_t n = static_cast<size_t>(ctx->n_pts);
     std::vector<double> x(n), y(n), z(n);
     if (n) {
-        C5_HIP(ctx, hipMemcpy(x.data(), ctx->vx.ptr, n * 8, hipMemcpyDeviceToHost));
-        C5_HIP(ctx, hipMemcpy(y.data(), ctx->vy.ptr, n * 8, hipMemcpyDeviceToHost));
-        C5_HIP(ctx, hipMemcpy(z.data(), ctx->vz.ptr, n * 8, hipMemcpyDeviceToHost));
+        C5_HIP(ctx, hipMemcpy(x.data(), ctx->slots[ctx->last_slot].vx.ptr, n * 8, hipMemcpyDeviceToHost));
+        C5_HIP(ctx, hipMemcpy(y.data(), ctx->slots[ctx->last_slot].vy.ptr, n * 8, hipMemcpyDeviceToHost));
+        C5_HIP(ctx, hipMemcpy(z.data(), ctx->slots[ctx->last_slot].vz.ptr, n * 8, hipMemcpyDeviceToHost));
     }
     for (size_t i = 0; i < n; ++i) {
         xyz[3 * i] = x[i];

@@ -23,7 +23,10 @@ from . import sharding
 
 class FramePipeline:
     def __init__(self, res_x: int, res_y: int, rank: int, world: int, device, depth: int = 2,
-                 tile_rows: int = 16, blocks=None):
+                 tile_rows: int = 16, blocks=None, host_staging: bool = False):
+        """host_staging: rehearsal only (gloo backend, which cannot gather device tensors): strips
+        take a round trip through host memory around the gather."""
+        self.host_staging = host_staging
         self.res_x, self.res_y, self.tile_rows = res_x, res_y, tile_rows
         self.rank, self.world, self.device = rank, world, device
         self.blocks = list(blocks) if blocks is not None else None
@@ -68,7 +71,17 @@ class FramePipeline:
         if self.world == 1:
             self.frame = self.strips[s]
             return
-        work = dist.gather(self.strips[s], self.parts[s] if self.rank == 0 else None, dst=0, async_op=True)
+        if self.host_staging:
+            torch.cuda.current_stream().synchronize()
+            host = self.strips[s].cpu()
+            got = [torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(host, got, dst=0)
+            if self.rank == 0:
+                for r in range(self.world):
+                    self.parts[s][r].copy_(got[r])
+            work = _Done()
+        else:
+            work = dist.gather(self.strips[s], self.parts[s] if self.rank == 0 else None, dst=0, async_op=True)
         self.pending.append((work, s))
         if len(self.pending) >= self.depth:
             self._finish(self.pending.pop(0))
@@ -77,6 +90,11 @@ class FramePipeline:
         while self.pending:
             self._finish(self.pending.pop(0))
         return self.frame
+
+
+class _Done:
+    def wait(self):
+        return True
 
 
 def gather_row_costs(local_costs: np.ndarray, blocks, rank: int, world: int, device) -> np.ndarray:

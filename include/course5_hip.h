@@ -142,6 +142,9 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  record once and stages it through LDS; 0: every lane loads its own record.
  *   "tile"         wavefront tile: 0 = 64x1 row tile, 1 = 16x4, 2 = 8x8 pixels.
  *   "xcd_mode"     1 (default): 32-row bands dealt round-robin to the 8 XCDs; 0: row-major tiles.
+ *   "pipeline"     1: two frame slots; the per-view setup of frame k + 1 runs on a second stream while
+ *                  frame k is walked (set before c5_upload_grid / c5_set_image).  Default 0: on
+ *                  MI355X the walk already fills the GPU and the overlap measured slower.
  *   "row_costs"    1: walk_composite also accumulates segments per image row (c5_get_row_costs).
  *   "stage_timing" / "walk_timing"  0/1: record HIP events per stage / around walk_composite. */
 int c5_set_option(c5_context* ctx, const char* name, double value);

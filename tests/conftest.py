@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# torch ships its own HIP runtime; it must be loaded before libcourse5_hip.so pulls in the system
+# one, or torch later finds no GPU in this process (tests that hand torch tensors to the C ABI).
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
