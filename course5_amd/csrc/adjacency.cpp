@@ -1,6 +1,7 @@
 #include "adjacency.hpp"
 
 #include <algorithm>
+#include <cstring>
 
 namespace c5 {
 
@@ -63,6 +64,81 @@ bool build_face_adjacency(const int32_t* cell_vert, int64_t n_cells, int64_t n_p
     }
     std::sort(bfaces.begin(), bfaces.end());
     return true;
+}
+
+void unique_solid_faces(const double* tets, int64_t n_tets, std::vector<double>& points,
+                        std::vector<int32_t>& faces) {
+    static const int FV[4][3] = {{0, 1, 2}, {0, 1, 3}, {0, 2, 3}, {1, 2, 3}};
+    const int64_t n_raw = 4 * n_tets;
+    // 1. unique points: sort raw point indices by the bit patterns of (x, y, z)
+    auto bits = [](double v) {
+        uint64_t u;
+        std::memcpy(&u, &v, sizeof u);
+        return u;
+    };
+    std::vector<uint32_t> order(static_cast<size_t>(n_raw));
+    for (int64_t i = 0; i < n_raw; ++i) order[static_cast<size_t>(i)] = static_cast<uint32_t>(i);
+    auto pt_less = [&](uint32_t l, uint32_t r) {
+        for (int k = 0; k < 3; ++k) {
+            const uint64_t a = bits(tets[3 * static_cast<size_t>(l) + k]), b = bits(tets[3 * static_cast<size_t>(r) + k]);
+            if (a != b) return a < b;
+        }
+        return false;
+    };
+    auto pt_eq = [&](uint32_t l, uint32_t r) {
+        for (int k = 0; k < 3; ++k)
+            if (bits(tets[3 * static_cast<size_t>(l) + k]) != bits(tets[3 * static_cast<size_t>(r) + k])) return false;
+        return true;
+    };
+    std::sort(order.begin(), order.end(), pt_less);
+    std::vector<int32_t> id_of(static_cast<size_t>(n_raw));
+    points.clear();
+    for (size_t i = 0; i < order.size(); ++i) {
+        if (i == 0 || !pt_eq(order[i - 1], order[i])) {
+            for (int k = 0; k < 3; ++k) points.push_back(tets[3 * static_cast<size_t>(order[i]) + k]);
+        }
+        id_of[order[i]] = static_cast<int32_t>(points.size() / 3 - 1);
+    }
+    // 2. unique faces
+    std::vector<FaceKey> keys(static_cast<size_t>(n_raw));
+    for (int64_t t = 0; t < n_tets; ++t) {
+        for (int f = 0; f < 4; ++f) {
+            uint32_t v[3] = {static_cast<uint32_t>(id_of[static_cast<size_t>(4 * t + FV[f][0])]),
+                             static_cast<uint32_t>(id_of[static_cast<size_t>(4 * t + FV[f][1])]),
+                             static_cast<uint32_t>(id_of[static_cast<size_t>(4 * t + FV[f][2])])};
+            if (v[0] > v[1]) std::swap(v[0], v[1]);
+            if (v[1] > v[2]) std::swap(v[1], v[2]);
+            if (v[0] > v[1]) std::swap(v[0], v[1]);
+            keys[static_cast<size_t>(4 * t + f)] = FaceKey{v[0], v[1], v[2], static_cast<uint32_t>(4 * t + f)};
+        }
+    }
+    std::sort(keys.begin(), keys.end(), [](const FaceKey& l, const FaceKey& r) {
+        if (l.a != r.a) return l.a < r.a;
+        if (l.b != r.b) return l.b < r.b;
+        if (l.c != r.c) return l.c < r.c;
+        return l.ref < r.ref;
+    });
+    // keep the first occurrence of every face, then restore the generator's order: consecutive cells
+    // of init_polar are angular neighbours, so consecutive faces cover neighbouring pixels of the same
+    // image rows (coalesced mask accesses); faces through vertex 0 (the fan centre: long slivers) go
+    // first and the short surface faces (slot 3) last, so a wavefront holds faces of similar height.
+    std::vector<FaceKey> uniq;
+    uniq.reserve(keys.size());
+    for (size_t i = 0; i < keys.size(); ++i)
+        if (i == 0 || !key_eq(keys[i - 1], keys[i])) uniq.push_back(keys[i]);
+    std::sort(uniq.begin(), uniq.end(), [](const FaceKey& l, const FaceKey& r) {
+        const bool ls = (l.ref & 3u) == 3u, rs = (r.ref & 3u) == 3u;
+        if (ls != rs) return !ls;
+        return l.ref < r.ref;
+    });
+    faces.clear();
+    faces.reserve(4 * uniq.size());
+    for (const FaceKey& k : uniq) {
+        faces.push_back(static_cast<int32_t>(k.a));
+        faces.push_back(static_cast<int32_t>(k.b));
+        faces.push_back(static_cast<int32_t>(k.c));
+        faces.push_back(0);
+    }
 }
 
 }  // namespace c5

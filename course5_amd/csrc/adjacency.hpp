@@ -15,4 +15,11 @@ namespace c5 {
 bool build_face_adjacency(const int32_t* cell_vert, int64_t n_cells, int64_t n_pts,
                           std::vector<int32_t>& adj, std::vector<uint32_t>& bfaces, std::string& err);
 
+// Solid tet soup [n][4][3] -> unique points (bitwise equal coordinates merged) and unique faces
+// (unordered point-id triples; 4 per tet before merging).  The centre-fan solids of the reference
+// (object3d_base.cpp:152-193) share every sliver face between two cells and every point between ~24,
+// and the mask raster only depends on a face's three points, so duplicates are pure overdraw.
+void unique_solid_faces(const double* tets, int64_t n_tets, std::vector<double>& points,
+                        std::vector<int32_t>& faces /* 4 ints per face: a, b, c, 0 */);
+
 }  // namespace c5

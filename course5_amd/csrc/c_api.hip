@@ -48,10 +48,13 @@ struct DeviceBuffer {
 };
 
 struct Solid {
-    int64_t n_tets = 0;
+    int64_t n_tets = 0;      // as given
+    int64_t n_points = 0;    // unique points
+    int64_t n_faces = 0;     // unique faces
     double colour = 0.0;
-    DeviceBuffer raw;        // [n][4][3] doubles, as given
-    DeviceBuffer view[2];    // transformed copy, one per frame slot
+    DeviceBuffer raw;        // unique points [m][3]
+    DeviceBuffer faces;      // unique faces, int4 (a, b, c, 0)
+    DeviceBuffer view[2];    // transformed points, one per frame slot
     c5::RotationList rots{};
 };
 
@@ -292,25 +295,20 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     // (a9) solids
     c5::SolidTable table{};
     bool any_solid = false;
-    uint32_t next_id = 0;
     for (int k = 0; k < C5_MAX_SOLIDS; ++k) {
-        table.first_id[k] = next_id;
         table.colour[k] = ctx->solids[k].colour;
-        if (ctx->solids[k].n_tets > 0) {
-            any_solid = true;
-            next_id += static_cast<uint32_t>(ctx->solids[k].n_tets);
-        }
+        if (ctx->solids[k].n_tets > 0) any_solid = true;
     }
-    table.first_id[C5_MAX_SOLIDS] = next_id;
     table.n_slots = C5_MAX_SOLIDS;
     if (any_solid) {
         C5_HIP(ctx, hipMemsetAsync(fs.mask.ptr, 0, static_cast<size_t>(padded) * sizeof(uint32_t), s));
         for (int k = 0; k < C5_MAX_SOLIDS; ++k) {
             Solid& so = ctx->solids[k];
             if (so.n_tets <= 0) continue;
-            c5::launch_transform_aos(s, so.raw.as<double>(), so.view[slot_id].as<double>(), 4 * so.n_tets, so.rots);
-            c5::launch_solid_mask_raster(s, so.view[slot_id].as<double>(), so.n_tets, table.first_id[k],
-                                         ctx->ytab.as<double>(), im, fs.mask.as<uint32_t>());
+            c5::launch_transform_aos(s, so.raw.as<double>(), so.view[slot_id].as<double>(), so.n_points, so.rots);
+            c5::launch_solid_mask_raster(s, so.view[slot_id].as<double>(), so.faces.as<int4>(), so.n_faces,
+                                         static_cast<uint32_t>(k) + 1u, ctx->ytab.as<double>(), im,
+                                         fs.mask.as<uint32_t>());
         }
     }
     C5_HIP(ctx, mark(4, s));
@@ -505,6 +503,7 @@ void c5_destroy(c5_context* ctx) {
     }
     for (Solid& so : ctx->solids) {
         so.raw.release();
+        so.faces.release();
         for (DeviceBuffer& v : so.view) v.release();
     }
     for (int k = 0; k < kWalkEventPool; ++k) {
@@ -623,11 +622,19 @@ int c5_set_solid(c5_context* ctx, int slot, const double* tets, int64_t n_tets, 
         return fail(ctx, C5_ERR_INVALID, "solid cell count does not fit 28 bits");
     s.n_tets = n_tets;
     s.colour = colour;
+    s.n_points = s.n_faces = 0;
     if (n_tets > 0) {
-        const size_t bytes = static_cast<size_t>(n_tets) * 12 * sizeof(double);
+        std::vector<double> pts;
+        std::vector<int32_t> faces;
+        c5::unique_solid_faces(tets, n_tets, pts, faces);
+        s.n_points = static_cast<int64_t>(pts.size() / 3);
+        s.n_faces = static_cast<int64_t>(faces.size() / 4);
+        const size_t bytes = pts.size() * sizeof(double);
         C5_HIP(ctx, s.raw.ensure(bytes));
+        C5_HIP(ctx, s.faces.ensure(faces.size() * sizeof(int32_t)));
         for (int k = 0; k < (ctx->pipeline ? kFrameSlots : 1); ++k) C5_HIP(ctx, s.view[k].ensure(bytes));
-        C5_HIP(ctx, hipMemcpy(s.raw.ptr, tets, bytes, hipMemcpyHostToDevice));
+        C5_HIP(ctx, hipMemcpy(s.raw.ptr, pts.data(), bytes, hipMemcpyHostToDevice));
+        C5_HIP(ctx, hipMemcpy(s.faces.ptr, faces.data(), faces.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     return C5_OK;
 }

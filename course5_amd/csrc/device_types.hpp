@@ -72,8 +72,7 @@ struct ImageParams {
 constexpr int kMaxSolids = 8;
 struct SolidTable {
     int32_t n_slots;
-    uint32_t first_id[kMaxSolids + 1];  // mask value v (>0) belongs to slot s if first_id[s] < v <= first_id[s+1]
-    double colour[kMaxSolids];
+    double colour[kMaxSolids];  // mask value v > 0 means "covered by solid slot v - 1"
 };
 
 struct FrameCounters {
@@ -90,12 +89,14 @@ struct FrameCounters {
 __host__ __device__ inline int local_row_of(const ImageParams& im, int row) {
     const int r = row - im.row_begin;
     if (r < 0 || r >= im.row_count) return -1;
+    if (im.world == 1) return r;  // no integer divisions on the common path
     const int tile = r / im.tile_rows;
     if (tile % im.world != im.rank) return -1;
     return (tile / im.world) * im.tile_rows + (r - tile * im.tile_rows);
 }
 // local row -> global row
 __host__ __device__ inline int global_row_of(const ImageParams& im, int lrow) {
+    if (im.world == 1) return im.row_begin + lrow;
     const int ltile = lrow / im.tile_rows;
     return im.row_begin + (ltile * im.world + im.rank) * im.tile_rows + (lrow - ltile * im.tile_rows);
 }

@@ -50,8 +50,8 @@ void launch_transform_soa(hipStream_t s, const double* px, const double* py, con
                           double* vx, double* vy, double* vz, int64_t n, const RotationList& R);
 void launch_transform_aos(hipStream_t s, const double* in, double* out, int64_t n,
                           const RotationList& R);
-void launch_solid_mask_raster(hipStream_t s, const double* tets, int64_t n_tets, uint32_t first_id,
-                              const double* Ytab, const ImageParams& im, uint32_t* mask);
+void launch_solid_mask_raster(hipStream_t s, const double* pts, const int4* faces, int64_t n_faces,
+                              uint32_t value, const double* Ytab, const ImageParams& im, uint32_t* mask);
 
 // walk_kernels.hip
 void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit);

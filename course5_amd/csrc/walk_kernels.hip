@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
             // line.cpp:177-179,197-199: a solid-marked pixel returns the mark on both channels
             double colour = 0.0;
             for (int s = 0; s < P.solids.n_slots; ++s)
-                if (mv > P.solids.first_id[s] && mv <= P.solids.first_id[s + 1]) colour = P.solids.colour[s];
+                if (mv == static_cast<uint32_t>(s) + 1u) colour = P.solids.colour[s];
             result.x = static_cast<float>(colour);
             result.y = result.x;
             is_solid = 1;
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256) void walk_composite_lds(WalkParams P) {
         if (mv) {
             double colour = 0.0;
             for (int s = 0; s < P.solids.n_slots; ++s)
-                if (mv > P.solids.first_id[s] && mv <= P.solids.first_id[s + 1]) colour = P.solids.colour[s];
+                if (mv == static_cast<uint32_t>(s) + 1u) colour = P.solids.colour[s];
             result.x = static_cast<float>(colour);
             result.y = result.x;
             is_solid = 1;
