@@ -276,7 +276,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     c5::launch_transform_soa(s, g.px, g.py, g.pz, g.vx, g.vy, g.vz, g.n_pts, ctx->view);
     C5_HIP(ctx, mark(1, s));
     // (a1, a10, a13 constants) per-cell records
-    c5::launch_build_records(s, g, ctx->alpha_limit);
+    c5::launch_build_records(s, g, ctx->alpha_limit, ctx->order);
     C5_HIP(ctx, mark(2, s));
     // boundary entries: count -> scan -> fill
     C5_HIP(ctx, hipMemsetAsync(fs.count.ptr, 0, static_cast<size_t>(padded + 1) * sizeof(int32_t), s));

@@ -21,25 +21,34 @@ namespace c5 {
 
 constexpr uint32_t kIdMask = 0x0FFFFFFFu;   // 28-bit cell id (line.hpp:71-79, line.cpp:27)
 constexpr uint32_t kNoCell = 0x0FFFFFFFu;   // neighbour field of a boundary face
-constexpr uint32_t kFaceUpper = 0x80000000u;  // cell body lies below the face plane (ray enters here when walking -z)
-constexpr uint32_t kFaceSkip = 0x40000000u;   // face is edge-on to the rays (no z(x,y)) or cell is flat
+constexpr int kUpperCountShift = 30;        // nbr[0] bits 30-31: number of "upper" slots (1..3)
 
-// z of face k at pixel (x, y):  z = plane[k][0] + plane[k][1] * (x - x0) + plane[k][2] * (y - y0)
+// One walk step needs, per face, z(x, y) = plane[k][0] + plane[k][1] * (x - x0) + plane[k][2] * (y - y0)
 // (line::find_polygon_intersection_z, line.cpp:150-174, rewritten about the cell-local origin
-// (x0, y0) = vertex 0 so the 128-byte record holds all four faces).
+// (x0, y0) = vertex 0 so that the 128-byte record holds all four faces) and the neighbour behind it.
+//
+// The four faces are stored in WALK ORDER, not in the reference's face numbering: first the
+// n_up "upper" faces (the cell body lies below their plane), then the "lower" ones, so the kernel
+// classifies a slot by its position.  z_top = min over upper slots, z_bot = max over lower slots are
+// the two faces the reference pairs for a pixel inside the cell's projection (line.cpp:99-131).
+// Faces that are edge-on to the rays (no z(x, y)) are stored as upper slots with plane +inf so they
+// never win; a flat cell gets +inf / -inf in slots 0 / 3 and therefore neither contributes nor
+// forwards the ray.
 struct alignas(16) CellRecord {
     double x0, y0;
     double plane[4][3];
-    uint32_t nbr[4];  // kIdMask bits: neighbour cell or kNoCell; kFaceUpper / kFaceSkip flags
+    uint32_t nbr[4];  // kIdMask bits: neighbour cell or kNoCell; nbr[0] also carries n_up
 };
 static_assert(sizeof(CellRecord) == 128, "CellRecord must be one 128-byte line");
 
 // line.cpp:204-224 folded per cell: alpha_c = min(alpha, limit); cells with alpha_c < DBL_EPSILON
-// neither absorb nor emit (alpha_c = 0, source = 0); otherwise source = Q / alpha_c.
+// neither absorb nor emit (alpha_c = 0).  `aux` is what the chosen integration order multiplies by:
+// 1 / alpha_c for the reference's recurrence (its final division, as a reciprocal: <= 1 ulp apart),
+// Q / alpha_c (the source function) for the front-to-back sum.
 struct alignas(16) CellOptics {
     double alpha_raw;  // ch0 uses the unclamped value (line.cpp:189)
     double alpha_c;
-    double source;
+    double aux;
     double q;
 };
 static_assert(sizeof(CellOptics) == 32, "CellOptics is 32 bytes");

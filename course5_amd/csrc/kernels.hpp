@@ -54,7 +54,7 @@ void launch_solid_mask_raster(hipStream_t s, const double* pts, const int4* face
                               uint32_t value, const double* Ytab, const ImageParams& im, uint32_t* mask);
 
 // walk_kernels.hip
-void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit);
+void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, int order);
 void launch_entry_count(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
                         const ImageParams& im, int32_t* count, int want_upper);
 void launch_entry_fill(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,

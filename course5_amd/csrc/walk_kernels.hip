@@ -28,7 +28,37 @@ namespace c5 {
 // ------------------------------------------------------------------------------------------
 // build_records
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void build_records(GridView g, double alpha_limit) {
+struct FacePlane {
+    double c, gx, gy;  // z = c + gx (x - x0) + gy (y - y0)
+    int kind;          // +1 upper (cell body below the plane), -1 lower, 0 edge-on / flat
+};
+
+// Plane of face f of a cell with transformed vertices p[4], about the origin (x0, y0) = p[0].xy.
+// Faces and vertex order as in the reference (plane.cpp:30-37, line.cpp:103-122):
+//   0 = (0,1,2)  1 = (0,1,3)  2 = (0,2,3)  3 = (1,2,3);  z from line.cpp:158-171.
+// Used by build_records and entry_raster so that an entry's z and the walk's z are the same numbers.
+__device__ __forceinline__ FacePlane face_plane(const double (&p)[4][3], int f) {
+    constexpr int FV[4][4] = {{0, 1, 2, 3}, {0, 1, 3, 2}, {0, 2, 3, 1}, {1, 2, 3, 0}};
+    const double* a = p[FV[f][0]];
+    const double* b = p[FV[f][1]];
+    const double* c = p[FV[f][2]];
+    const double* o = p[FV[f][3]];
+    const double x0 = p[0][0], y0 = p[0][1];
+    // line.cpp:158-171: z = ((y-ay)*A - (x-ax)*B)/m + az
+    const double A = (b[0] - a[0]) * (c[2] - a[2]) - (c[0] - a[0]) * (b[2] - a[2]);
+    const double B = (b[1] - a[1]) * (c[2] - a[2]) - (c[1] - a[1]) * (b[2] - a[2]);
+    const double m = (b[0] - a[0]) * (c[1] - a[1]) - (c[0] - a[0]) * (b[1] - a[1]);
+    FacePlane r;
+    r.gy = A / m;
+    r.gx = -B / m;
+    r.c = a[2] + r.gx * (x0 - a[0]) + r.gy * (y0 - a[1]);
+    const double z_under_opp = r.c + r.gx * (o[0] - x0) + r.gy * (o[1] - y0);
+    const bool finite = (fabs(r.gx) <= DBL_MAX) && (fabs(r.gy) <= DBL_MAX) && (fabs(r.c) <= DBL_MAX);
+    r.kind = (!finite || !(o[2] != z_under_opp)) ? 0 : (o[2] < z_under_opp ? 1 : -1);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void build_records(GridView g, double alpha_limit, int order) {
     const int64_t cell = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
     if (cell >= g.n_cells) return;
     const int4 cv = g.cell_vert[cell];
@@ -48,37 +78,70 @@ __global__ __launch_bounds__(256) void build_records(GridView g, double alpha_li
         p[k][0] = g.vx[vid[k]];
         p[k][2] = g.vz[vid[k]];
     }
+
+    FacePlane fp[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) fp[f] = face_plane(p, f);
+    int n_true_up = 0, n_lo = 0, n_edge_on = 0;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        n_true_up += (fp[f].kind > 0) ? 1 : 0;
+        n_lo += (fp[f].kind < 0) ? 1 : 0;
+        n_edge_on += (fp[f].kind == 0) ? 1 : 0;
+    }
+    const int n_up = n_true_up + n_edge_on;  // edge-on faces ride along in the upper group (plane +inf)
+    const bool flat = (n_lo == 0) || (n_true_up == 0);
+
+    // walk order: upper (and edge-on) faces first, lower faces last; everything selected, nothing indexed
     CellRecord r;
     r.x0 = p[0][0];
     r.y0 = p[0][1];
-    // faces in the reference's numbering and vertex order (plane.cpp:30-37, line.cpp:103-122)
-    constexpr int FV[4][4] = {{0, 1, 2, 3}, {0, 1, 3, 2}, {0, 2, 3, 1}, {1, 2, 3, 0}};
+    int up_pos = 0, lo_pos = n_up;
+    uint32_t words[4] = {kNoCell, kNoCell, kNoCell, kNoCell};
+    double pl[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pl[j][0] = pl[j][1] = pl[j][2] = 0.0;
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
-        const double* a = p[FV[f][0]];
-        const double* b = p[FV[f][1]];
-        const double* c = p[FV[f][2]];
-        const double* o = p[FV[f][3]];
-        // line.cpp:158-171: z = ((y-ay)*A - (x-ax)*B)/m + az
-        const double A = (b[0] - a[0]) * (c[2] - a[2]) - (c[0] - a[0]) * (b[2] - a[2]);
-        const double B = (b[1] - a[1]) * (c[2] - a[2]) - (c[1] - a[1]) * (b[2] - a[2]);
-        const double m = (b[0] - a[0]) * (c[1] - a[1]) - (c[0] - a[0]) * (b[1] - a[1]);
-        const double gy = A / m;
-        const double gx = -B / m;
-        const double c0 = a[2] + gx * (r.x0 - a[0]) + gy * (r.y0 - a[1]);
-        const double z_under_opp = c0 + gx * (o[0] - r.x0) + gy * (o[1] - r.y0);
-        uint32_t w = (nb[f] < 0) ? kNoCell : (static_cast<uint32_t>(nb[f]) & kIdMask);
-        const bool finite = (fabs(gx) <= DBL_MAX) && (fabs(gy) <= DBL_MAX) && (fabs(c0) <= DBL_MAX);
-        if (!finite || !(o[2] != z_under_opp)) {
-            w |= kFaceSkip;
-        } else if (o[2] < z_under_opp) {
-            w |= kFaceUpper;
+        const bool up = fp[f].kind >= 0;
+        const int pos = up ? up_pos : lo_pos;
+        up_pos += up ? 1 : 0;
+        lo_pos += up ? 0 : 1;
+        const uint32_t w = (nb[f] < 0) ? kNoCell : (static_cast<uint32_t>(nb[f]) & kIdMask);
+        const double c = (fp[f].kind == 0) ? INFINITY : fp[f].c;
+        const double gx = (fp[f].kind == 0) ? 0.0 : fp[f].gx;
+        const double gy = (fp[f].kind == 0) ? 0.0 : fp[f].gy;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j == pos) {
+                pl[j][0] = c;
+                pl[j][1] = gx;
+                pl[j][2] = gy;
+                words[j] = w;
+            }
         }
-        r.plane[f][0] = finite ? c0 : 0.0;
-        r.plane[f][1] = finite ? gx : 0.0;
-        r.plane[f][2] = finite ? gy : 0.0;
-        r.nbr[f] = w;
     }
+    int stored_up = n_up;
+    if (flat) {
+        // no interior along z: neither contributes nor forwards the ray
+        pl[0][0] = INFINITY;
+        pl[0][1] = pl[0][2] = 0.0;
+        pl[3][0] = -INFINITY;
+        pl[3][1] = pl[3][2] = 0.0;
+        pl[1][0] = INFINITY;
+        pl[1][1] = pl[1][2] = 0.0;
+        pl[2][0] = -INFINITY;
+        pl[2][1] = pl[2][2] = 0.0;
+        stored_up = 2;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r.plane[j][0] = pl[j][0];
+        r.plane[j][1] = pl[j][1];
+        r.plane[j][2] = pl[j][2];
+        r.nbr[j] = words[j];
+    }
+    r.nbr[0] |= static_cast<uint32_t>(stored_up) << kUpperCountShift;
     g.rec[cell] = r;
 
     // line.cpp:204-224
@@ -91,18 +154,18 @@ __global__ __launch_bounds__(256) void build_records(GridView g, double alpha_li
     o.q = qv;
     if (a_c < DBL_EPSILON) {
         o.alpha_c = 0.0;
-        o.source = 0.0;
+        o.aux = 0.0;
     } else {
         o.alpha_c = a_c;
-        o.source = qv / a_c;
+        o.aux = (order == 0) ? 1.0 / a_c : qv / a_c;
     }
     g.opt[cell] = o;
 }
 
-void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit) {
+void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, int order) {
     if (g.n_cells <= 0) return;
     const unsigned blocks = static_cast<unsigned>((g.n_cells + 255) / 256);
-    hipLaunchKernelGGL(build_records, dim3(blocks), dim3(256), 0, s, g, alpha_limit);
+    hipLaunchKernelGGL(build_records, dim3(blocks), dim3(256), 0, s, g, alpha_limit, order);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -121,25 +184,43 @@ __global__ __launch_bounds__(256) void entry_raster(GridView g, const double* __
     const uint32_t bf = g.bface[face_idx];
     const uint32_t cell = bf >> 2;
     const int f = static_cast<int>(bf & 3u);
-    const CellRecord* rec = g.rec + cell;
-    {   // same band test as build_records: a culled cell has no record
-        const int4 cv0 = g.cell_vert[cell];
-        const double y0 = g.vy[cv0.x], y1 = g.vy[cv0.y], y2 = g.vy[cv0.z], y3 = g.vy[cv0.w];
-        if (fmax(fmax(y0, y1), fmax(y2, y3)) < g.cull_y_lo || fmin(fmin(y0, y1), fmin(y2, y3)) > g.cull_y_hi) return;
-    }
-    const uint32_t w = rec->nbr[f];
-    // walking from +z to -z a ray enters through faces the cell body lies below (upper faces);
-    // walking from -z to +z through the others
-    if ((w & kFaceSkip) || (((w & kFaceUpper) != 0) != (want_upper != 0))) return;
-
     const int4 cv = g.cell_vert[cell];
     const int vid[4] = {cv.x, cv.y, cv.z, cv.w};
+    double p[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p[k][1] = g.vy[vid[k]];
+    // same band test as build_records: a culled cell has no record and no ray of this context
+    if (fmax(fmax(p[0][1], p[1][1]), fmax(p[2][1], p[3][1])) < g.cull_y_lo ||
+        fmin(fmin(p[0][1], p[1][1]), fmin(p[2][1], p[3][1])) > g.cull_y_hi)
+        return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        p[k][0] = g.vx[vid[k]];
+        p[k][2] = g.vz[vid[k]];
+    }
+    FacePlane fp;
+    switch (f) {  // constant face index per case keeps the vertex selection in registers
+        case 0: fp = face_plane(p, 0); break;
+        case 1: fp = face_plane(p, 1); break;
+        case 2: fp = face_plane(p, 2); break;
+        default: fp = face_plane(p, 3); break;
+    }
+    // walking from +z to -z a ray enters through faces the cell body lies below (upper faces);
+    // walking from -z to +z through the others
+    if (fp.kind == 0 || ((fp.kind > 0) != (want_upper != 0))) return;
+
     const int i0 = (f == 3) ? 1 : 0;
     const int i1 = (f <= 1) ? 1 : 2;
     const int i2 = (f == 0) ? 2 : 3;
-    const double ax = g.vx[vid[i0]], ay = g.vy[vid[i0]];
-    const double bx = g.vx[vid[i1]], by = g.vy[vid[i1]];
-    const double cx = g.vx[vid[i2]], cy = g.vy[vid[i2]];
+    double ax, ay, bx, by, cx, cy;
+    {   // selects, not runtime indexing
+        ax = i0 == 0 ? p[0][0] : p[1][0];
+        ay = i0 == 0 ? p[0][1] : p[1][1];
+        bx = i1 == 1 ? p[1][0] : p[2][0];
+        by = i1 == 1 ? p[1][1] : p[2][1];
+        cx = i2 == 2 ? p[2][0] : p[3][0];
+        cy = i2 == 2 ? p[2][1] : p[3][1];
+    }
 
     const double xmin = fmin(ax, fmin(bx, cx)), xmax = fmax(ax, fmax(bx, cx));
     const double ymin = fmin(ay, fmin(by, cy)), ymax = fmax(ay, fmax(by, cy));
@@ -157,8 +238,8 @@ __global__ __launch_bounds__(256) void entry_raster(GridView g, const double* __
     const int bw = c1 - c0 + 1;
     const int64_t n_box = static_cast<int64_t>(bw) * (r1 - r0 + 1);
 
-    const double x0 = rec->x0, y0 = rec->y0;
-    const double pc = rec->plane[f][0], pgx = rec->plane[f][1], pgy = rec->plane[f][2];
+    const double x0 = p[0][0], y0 = p[0][1];
+    const double pc = fp.c, pgx = fp.gx, pgy = fp.gy;
 
     for (int64_t idx = lane; idx < n_box; idx += 64) {
         const int row = r0 + static_cast<int>(idx / bw);
@@ -337,13 +418,29 @@ struct alignas(16) D2 {
 //   C = Q - alpha * I;   I = (Q - C * exp(-alpha * dz)) / alpha
 // with every product and sum rounded separately (no FMA contraction), so that the recurrence —
 // including its cancellation noise for tiny alpha — follows the reference's to the last bits of exp.
-__device__ __forceinline__ double reference_emission_step(double I, double alpha_c, double q, double dz) {
+// The final division is a multiplication by the per-cell reciprocal (<= 1 ulp apart, not amplified).
+__device__ __forceinline__ double reference_emission_step(double I, double alpha_c, double q, double inv_alpha,
+                                                          double dz) {
 #pragma clang fp contract(off)
     const double C = q - alpha_c * I;
     const double arg = -alpha_c * dz;
     const double e = exp(arg);
-    return (q - C * e) / alpha_c;
+    return (q - C * e) * inv_alpha;
 }
+
+// Geometry of one step: where the ray (x, y) crosses the current cell and through which face it
+// leaves.  Slots 0..n_up-1 of the record are upper faces, the rest lower (device_types.hpp).
+struct StepGeometry {
+    double dz;         // z_top - z_bot (line.cpp:124-131)
+    double s_exit;     // position of the exit face along the walk (z walking down, -z walking up)
+    uint32_t w_out;    // neighbour word of the exit face
+    bool contributes;  // the ray really crosses the cell
+    bool has_exit;
+};
+
+struct CellRegs;
+template <bool kUp>
+__device__ __forceinline__ StepGeometry step_geometry(const CellRegs& cur, double x, double y);
 
 // ORDER 0: walk from -z to +z and integrate back to front exactly like
 //          line::integrate_ray_value_by_i (the reference sorts by z_hi descending and runs the
@@ -376,6 +473,39 @@ __device__ __forceinline__ void load_cell(CellRegs& c, const CellRecord* rec, co
     c.r7 = rp[7];
     c.o0 = op[0];
     c.o1 = op[1];
+}
+
+template <bool kUp>
+__device__ __forceinline__ StepGeometry step_geometry(const CellRegs& cur, double x, double y) {
+    const double dx = x - cur.r0.a, dy = y - cur.r0.b;
+    // plane k = (c, gx, gy): r1.a r1.b r2.a | r2.b r3.a r3.b | r4.a r4.b r5.a | r5.b r6.a r6.b
+    const double z0 = fma(cur.r1.b, dx, fma(cur.r2.a, dy, cur.r1.a));
+    const double z1 = fma(cur.r3.a, dx, fma(cur.r3.b, dy, cur.r2.b));
+    const double z2 = fma(cur.r4.b, dx, fma(cur.r5.a, dy, cur.r4.a));
+    const double z3 = fma(cur.r6.a, dx, fma(cur.r6.b, dy, cur.r5.b));
+    const unsigned long long w01 = __double_as_longlong(cur.r7.a);
+    const unsigned long long w23 = __double_as_longlong(cur.r7.b);
+    const uint32_t w0 = static_cast<uint32_t>(w01), w1 = static_cast<uint32_t>(w01 >> 32);
+    const uint32_t w2 = static_cast<uint32_t>(w23), w3 = static_cast<uint32_t>(w23 >> 32);
+    const uint32_t n_up = w0 >> kUpperCountShift;  // 1..3: slot 0 is always upper, slot 3 always lower
+    const bool up1 = n_up > 1u, up2 = n_up > 2u;
+    const double u1 = up1 ? z1 : INFINITY, l1 = up1 ? -INFINITY : z1;
+    const double u2 = up2 ? z2 : INFINITY, l2 = up2 ? -INFINITY : z2;
+    const double z_top = fmin(z0, fmin(u1, u2));
+    const double z_bot = fmax(z3, fmax(l1, l2));
+    StepGeometry g;
+    g.dz = z_top - z_bot;
+    g.contributes = g.dz > 0.0 && g.dz < INFINITY;
+    if (kUp) {  // leaves through the lowest upper face
+        g.w_out = (z0 == z_top) ? w0 : (u1 == z_top) ? w1 : w2;
+        g.has_exit = z_top < INFINITY;
+        g.s_exit = -z_top;
+    } else {    // leaves through the highest lower face
+        g.w_out = (z3 == z_bot) ? w3 : (l2 == z_bot) ? w2 : w1;
+        g.has_exit = z_bot > -INFINITY;
+        g.s_exit = z_bot;
+    }
+    return g;
 }
 
 // next place the ray enters the grid beyond s_cur (s = z walking down, -z walking up); -1 if none
@@ -461,45 +591,14 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
     if (cell >= 0) load_cell(cur, P.rec, P.opt, cell);
 
     while (cell >= 0) {
-        const double dx = x - cur.r0.a, dy = y - cur.r0.b;
-        // plane k = (c, gx, gy): r1.a r1.b r2.a | r2.b r3.a r3.b | r4.a r4.b r5.a | r5.b r6.a r6.b
-        const double z0 = fma(cur.r1.b, dx, fma(cur.r2.a, dy, cur.r1.a));
-        const double z1 = fma(cur.r3.a, dx, fma(cur.r3.b, dy, cur.r2.b));
-        const double z2 = fma(cur.r4.b, dx, fma(cur.r5.a, dy, cur.r4.a));
-        const double z3 = fma(cur.r6.a, dx, fma(cur.r6.b, dy, cur.r5.b));
-        const unsigned long long w01 = __double_as_longlong(cur.r7.a);
-        const unsigned long long w23 = __double_as_longlong(cur.r7.b);
-        const uint32_t w0 = static_cast<uint32_t>(w01), w1 = static_cast<uint32_t>(w01 >> 32);
-        const uint32_t w2 = static_cast<uint32_t>(w23), w3 = static_cast<uint32_t>(w23 >> 32);
-
-        // The ray is inside the cell between the highest lower face and the lowest upper face:
-        // those are the two faces the reference pairs for this (pixel, tet) (line.cpp:99-131).
-        constexpr uint32_t kKind = kFaceUpper | kFaceSkip;
-        const double u0 = (w0 & kKind) == kFaceUpper ? z0 : DBL_MAX, l0 = (w0 & kKind) == 0u ? z0 : -DBL_MAX;
-        const double u1 = (w1 & kKind) == kFaceUpper ? z1 : DBL_MAX, l1 = (w1 & kKind) == 0u ? z1 : -DBL_MAX;
-        const double u2 = (w2 & kKind) == kFaceUpper ? z2 : DBL_MAX, l2 = (w2 & kKind) == 0u ? z2 : -DBL_MAX;
-        const double u3 = (w3 & kKind) == kFaceUpper ? z3 : DBL_MAX, l3 = (w3 & kKind) == 0u ? z3 : -DBL_MAX;
-        const double z_top = fmin(fmin(u0, u1), fmin(u2, u3));
-        const double z_bot = fmax(fmax(l0, l1), fmax(l2, l3));
-        // exit face = the one that realised the extremum (first in face order on ties)
-        uint32_t w_out;
-        bool has_exit;
-        if (kUp) {
-            w_out = (u0 == z_top) ? w0 : (u1 == z_top) ? w1 : (u2 == z_top) ? w2 : w3;
-            has_exit = z_top < DBL_MAX;
-        } else {
-            w_out = (l0 == z_bot) ? w0 : (l1 == z_bot) ? w1 : (l2 == z_bot) ? w2 : w3;
-            has_exit = z_bot > -DBL_MAX;
-        }
-        const double dz = z_top - z_bot;  // line.cpp:124-131
-        const bool contributes = dz > 0.0 && z_top < DBL_MAX && z_bot > -DBL_MAX;
+        const StepGeometry sg = step_geometry<kUp>(cur, x, y);
         ++n_step;
 
         // where next?
         int nb = -1;
-        if (has_exit) {
-            s_cur = fmin(s_cur, kUp ? -z_top : z_bot);
-            const uint32_t id = w_out & kIdMask;
+        if (sg.has_exit) {
+            s_cur = fmin(s_cur, sg.s_exit);
+            const uint32_t id = sg.w_out & kIdMask;
             if (id != kNoCell) nb = static_cast<int>(id);
         }
         if (nb >= 0 && n_step >= P.max_steps) {  // malformed grid: never spin
@@ -513,15 +612,15 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
         CellRegs nxt;
         if (nb >= 0) load_cell(nxt, P.rec, P.opt, nb);
 
-        if (contributes) {
+        if (sg.contributes) {
             ++n_seg;
-            tau = fma(dz, cur.o0.a, tau);  // line.cpp:189 (unclamped alpha)
+            tau = fma(sg.dz, cur.o0.a, tau);  // line.cpp:189 (unclamped alpha)
             if (ORDER == 0) {
                 // line.cpp:220-224 (NaN alpha propagates like there)
-                if (cur.o0.b != 0.0) I = reference_emission_step(I, cur.o0.b, cur.o1.b, dz);
+                if (cur.o0.b != 0.0) I = reference_emission_step(I, cur.o0.b, cur.o1.b, cur.o1.a, sg.dz);
             } else if (T >= P.t_cutoff) {
                 // I = sum_k T_k (Q/alpha)(1 - e^{-alpha dz}); T_{k+1} = T_k e^{-alpha dz}
-                const double ex = exp(-cur.o0.b * dz);
+                const double ex = exp(-cur.o0.b * sg.dz);
                 I = fma(T * cur.o1.a, 1.0 - ex, I);
                 T *= ex;
             }
@@ -648,7 +747,7 @@ __global__ __launch_bounds__(256) void walk_composite_lds(WalkParams P) {
 
     // contribution of the step whose record is being replaced (integrated while the next loads fly)
     bool pend = false;
-    double pend_dz = 0.0, pend_a_raw = 0.0, pend_a = 0.0, pend_s = 0.0;
+    double pend_dz = 0.0, pend_a_raw = 0.0, pend_a = 0.0, pend_aux = 0.0, pend_q = 0.0;
 
     while (true) {  // wave-uniform: every lane helps with the staging until all rays are done
         const bool need = nb >= 0;
@@ -684,10 +783,10 @@ __global__ __launch_bounds__(256) void walk_composite_lds(WalkParams P) {
             ++n_seg;
             tau = fma(pend_dz, pend_a_raw, tau);  // line.cpp:189
             if (ORDER == 0) {
-                if (pend_a != 0.0) I = reference_emission_step(I, pend_a, pend_s, pend_dz);  // line.cpp:220-224
+                if (pend_a != 0.0) I = reference_emission_step(I, pend_a, pend_q, pend_aux, pend_dz);  // line.cpp:220-224
             } else if (T >= P.t_cutoff) {
                 const double ex = exp(-pend_a * pend_dz);
-                I = fma(T * pend_s, 1.0 - ex, I);
+                I = fma(T * pend_aux, 1.0 - ex, I);
                 T *= ex;
             }
             pend = false;
@@ -720,44 +819,20 @@ __global__ __launch_bounds__(256) void walk_composite_lds(WalkParams P) {
                 load_cell(cur, P.rec, P.opt, nb);  // more distinct cells than slots: rare
             }
 
-            const double dx = x - cur.r0.a, dy = y - cur.r0.b;
-            const double z0 = fma(cur.r1.b, dx, fma(cur.r2.a, dy, cur.r1.a));
-            const double z1 = fma(cur.r3.a, dx, fma(cur.r3.b, dy, cur.r2.b));
-            const double z2 = fma(cur.r4.b, dx, fma(cur.r5.a, dy, cur.r4.a));
-            const double z3 = fma(cur.r6.a, dx, fma(cur.r6.b, dy, cur.r5.b));
-            const unsigned long long w01 = __double_as_longlong(cur.r7.a);
-            const unsigned long long w23 = __double_as_longlong(cur.r7.b);
-            const uint32_t w0 = static_cast<uint32_t>(w01), w1 = static_cast<uint32_t>(w01 >> 32);
-            const uint32_t w2 = static_cast<uint32_t>(w23), w3 = static_cast<uint32_t>(w23 >> 32);
-            constexpr uint32_t kKind = kFaceUpper | kFaceSkip;
-            const double u0 = (w0 & kKind) == kFaceUpper ? z0 : DBL_MAX, l0 = (w0 & kKind) == 0u ? z0 : -DBL_MAX;
-            const double u1 = (w1 & kKind) == kFaceUpper ? z1 : DBL_MAX, l1 = (w1 & kKind) == 0u ? z1 : -DBL_MAX;
-            const double u2 = (w2 & kKind) == kFaceUpper ? z2 : DBL_MAX, l2 = (w2 & kKind) == 0u ? z2 : -DBL_MAX;
-            const double u3 = (w3 & kKind) == kFaceUpper ? z3 : DBL_MAX, l3 = (w3 & kKind) == 0u ? z3 : -DBL_MAX;
-            const double z_top = fmin(fmin(u0, u1), fmin(u2, u3));
-            const double z_bot = fmax(fmax(l0, l1), fmax(l2, l3));
-            uint32_t w_out;
-            bool has_exit;
-            if (kUp) {
-                w_out = (u0 == z_top) ? w0 : (u1 == z_top) ? w1 : (u2 == z_top) ? w2 : w3;
-                has_exit = z_top < DBL_MAX;
-            } else {
-                w_out = (l0 == z_bot) ? w0 : (l1 == z_bot) ? w1 : (l2 == z_bot) ? w2 : w3;
-                has_exit = z_bot > -DBL_MAX;
-            }
-            const double dz = z_top - z_bot;  // line.cpp:124-131
+            const StepGeometry sg = step_geometry<kUp>(cur, x, y);
             ++n_step;
-            if (dz > 0.0 && z_top < DBL_MAX && z_bot > -DBL_MAX) {
+            if (sg.contributes) {
                 pend = true;
-                pend_dz = dz;
+                pend_dz = sg.dz;
                 pend_a_raw = cur.o0.a;
                 pend_a = cur.o0.b;
-                pend_s = (ORDER == 0) ? cur.o1.b : cur.o1.a;  // Q for the reference recurrence, Q/alpha otherwise
+                pend_aux = cur.o1.a;  // 1/alpha for the reference recurrence, Q/alpha otherwise
+                pend_q = cur.o1.b;
             }
             int nxt = -1;
-            if (has_exit) {
-                s_cur = fmin(s_cur, kUp ? -z_top : z_bot);
-                const uint32_t id = w_out & kIdMask;
+            if (sg.has_exit) {
+                s_cur = fmin(s_cur, sg.s_exit);
+                const uint32_t id = sg.w_out & kIdMask;
                 if (id != kNoCell) nxt = static_cast<int>(id);
             }
             if (nxt >= 0 && n_step >= P.max_steps) {
@@ -773,10 +848,10 @@ __global__ __launch_bounds__(256) void walk_composite_lds(WalkParams P) {
         ++n_seg;
         tau = fma(pend_dz, pend_a_raw, tau);
         if (ORDER == 0) {
-            if (pend_a != 0.0) I = reference_emission_step(I, pend_a, pend_s, pend_dz);
+            if (pend_a != 0.0) I = reference_emission_step(I, pend_a, pend_q, pend_aux, pend_dz);
         } else if (T >= P.t_cutoff) {
             const double ex = exp(-pend_a * pend_dz);
-            I = fma(T * pend_s, 1.0 - ex, I);
+            I = fma(T * pend_aux, 1.0 - ex, I);
             T *= ex;
         }
     }
