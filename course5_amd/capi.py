@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libcourse5_hip.so")
+LIB_PATH = os.environ.get("C5_LIB", os.path.join(PKG, "libcourse5_hip.so"))  # C5_LIB: A/B another build
 
 C5_OK, C5_ERR_INVALID, C5_ERR_STATE, C5_ERR_HIP, C5_ERR_MESH, C5_ERR_NO_DEVICE, C5_ERR_WALK, C5_RETRY = range(8)
 

@@ -98,7 +98,8 @@ struct c5_context {
     c5::ImageParams im{};
     int cfg_tile_rows = 0, cfg_rank = 0, cfg_world = 1;
     int cfg_row_begin = 0, cfg_row_count = -1;  // -1: all rows
-    DeviceBuffer xtab, ytab, out;
+    DeviceBuffer xtab, ytab, out, sticky;  // sticky: 2 x u32 failure words that persist across frames
+    unsigned* host_sticky = nullptr;       // pinned copy, refreshed at the end of every frame
     std::vector<double> host_ytab;
     int row_costs = 0;
 
@@ -285,7 +286,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
                                 ctx->order != 0);
     }
     c5::launch_exclusive_scan(s, fs.count.as<int32_t>(), fs.offs.as<int32_t>(), n_px, fs.scratch.as<int32_t>(),
-                              fs.counters.as<c5::FrameCounters>());
+                              fs.counters.as<c5::FrameCounters>(), ctx->sticky.as<unsigned>());
     if (g.n_cells > 0) {
         c5::launch_entry_fill(s, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im, fs.count.as<int32_t>(),
                               fs.offs.as<int32_t>(), fs.entries.as<c5::Entry>(), fs.entry_capacity,
@@ -332,6 +333,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     wp.lds_stage = ctx->lds_stage;
     wp.counters = fs.counters.as<c5::FrameCounters>();
     wp.row_cost = nullptr;
+    wp.sticky = ctx->sticky.as<unsigned>();
     if (ctx->row_costs && im.n_local_rows > 0) {
         wp.row_cost = fs.row_cost.as<uint32_t>();
         C5_HIP(ctx, hipMemsetAsync(fs.row_cost.ptr, 0, static_cast<size_t>(im.n_local_rows) * sizeof(uint32_t), s));
@@ -361,6 +363,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     C5_HIP(ctx, mark(5, main_s));
     C5_HIP(ctx, hipGetLastError());
     C5_HIP(ctx, hipMemcpyAsync(fs.host_counters, fs.counters.ptr, sizeof(c5::FrameCounters), hipMemcpyDeviceToHost, main_s));
+    C5_HIP(ctx, hipMemcpyAsync(ctx->host_sticky, ctx->sticky.ptr, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, main_s));
     if (ctx->pipeline) {
         C5_HIP(ctx, hipEventRecord(fs.walk_done, main_s));
         fs.walk_recorded = true;
@@ -391,21 +394,30 @@ int finish_frame(c5_context* ctx) {
         for (int k = 0; k < 5; ++k) C5_HIP(ctx, hipEventElapsedTime(dst[k], fs.ev[k], fs.ev[k + 1]));
         C5_HIP(ctx, hipEventElapsedTime(&st.ms_total, fs.ev[0], fs.ev[5]));
     }
-    if (hc.entry_overflow || static_cast<int64_t>(hc.entries) > fs.entry_capacity) {
-        st.entry_overflow += 1;
-        const int64_t want = static_cast<int64_t>(hc.entries) + static_cast<int64_t>(hc.entries) / 4 + 1024;
+    // failures of ANY frame since the last look (several frames may have been in flight)
+    const int64_t max_entries = static_cast<int64_t>(ctx->host_sticky[0]);
+    const unsigned lost_rays = ctx->host_sticky[1];
+    const bool too_small = max_entries > fs.entry_capacity;
+    if (too_small || lost_rays) {
         int rc = drain(ctx);
         if (rc) return rc;
-        for (FrameSlot& o : ctx->slots) {
+        C5_HIP(ctx, hipMemset(ctx->sticky.ptr, 0, 2 * sizeof(unsigned)));
+        ctx->host_sticky[0] = ctx->host_sticky[1] = 0;
+    }
+    if (too_small) {
+        st.entry_overflow += 1;
+        const int64_t want = max_entries + max_entries / 4 + 1024;
+        for (int k = 0; k < (ctx->pipeline ? kFrameSlots : 1); ++k) {
+            FrameSlot& o = ctx->slots[k];
             if (o.entry_capacity >= want) continue;
             o.entry_capacity = want;
             C5_HIP(ctx, o.entries.ensure(static_cast<size_t>(want) * sizeof(c5::Entry)));
         }
-        return fail(ctx, C5_RETRY, "entry buffer grown to %lld records; render the frame again",
+        return fail(ctx, C5_RETRY, "entry buffer grown to %lld records; render the frame(s) again",
                     static_cast<long long>(want));
     }
-    if (hc.walk_overflow)
-        return fail(ctx, C5_ERR_WALK, "%u rays exceeded the walk step bound (malformed grid?)", hc.walk_overflow);
+    if (lost_rays)
+        return fail(ctx, C5_ERR_WALK, "%u rays exceeded the walk step bound (malformed grid?)", lost_rays);
     return C5_OK;
 }
 
@@ -477,6 +489,11 @@ int c5_create(int device_ordinal, c5_context** out_ctx) {
         if ((e = hipEventCreate(&ctx->walk_a[k])) != hipSuccess) return bail(e, "hipEventCreate");
         if ((e = hipEventCreate(&ctx->walk_b[k])) != hipSuccess) return bail(e, "hipEventCreate");
     }
+    if ((e = ctx->sticky.ensure(2 * sizeof(unsigned))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMemset(ctx->sticky.ptr, 0, 2 * sizeof(unsigned))) != hipSuccess) return bail(e, "hipMemset");
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->host_sticky), 2 * sizeof(unsigned), hipHostMallocDefault)) != hipSuccess)
+        return bail(e, "hipHostMalloc");
+    ctx->host_sticky[0] = ctx->host_sticky[1] = 0;
     ctx->view.n = 0;
     for (Solid& s : ctx->solids) s.rots.n = 0;
     *out_ctx = ctx;
@@ -489,7 +506,8 @@ void c5_destroy(c5_context* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
     DeviceBuffer* bufs[] = {&ctx->px, &ctx->py, &ctx->pz, &ctx->cell_vert, &ctx->cell_adj, &ctx->alpha,
-                            &ctx->q, &ctx->bface, &ctx->xtab, &ctx->ytab, &ctx->out};
+                            &ctx->q, &ctx->bface, &ctx->xtab, &ctx->ytab, &ctx->out, &ctx->sticky};
+    if (ctx->host_sticky) (void)hipHostFree(ctx->host_sticky);
     for (DeviceBuffer* b : bufs) b->release();
     for (FrameSlot& fs : ctx->slots) {
         DeviceBuffer* sb[] = {&fs.vx, &fs.vy, &fs.vz, &fs.rec, &fs.opt, &fs.count, &fs.offs, &fs.scratch,

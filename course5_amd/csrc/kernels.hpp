@@ -43,6 +43,7 @@ struct WalkParams {
     int32_t order;              // 0: back to front in the reference's arithmetic; 1: front to back + early-out
     FrameCounters* counters;
     uint32_t* row_cost;         // [n_local_rows] segments per row of this frame, or nullptr
+    unsigned* sticky;           // [0] largest entry total, [1] rays over the step bound; reset by the host only
 };
 
 // exact_kernels.hip (-ffp-contract=off)
@@ -62,7 +63,7 @@ void launch_entry_fill(hipStream_t s, const GridView& g, const double* Xtab, con
                        int64_t capacity, FrameCounters* counters, int want_upper);
 // exclusive scan of count[n] into offs[n + 1]; scratch holds >= (n / 1024 + 2) int32
 void launch_exclusive_scan(hipStream_t s, const int32_t* count, int32_t* offs, int64_t n,
-                           int32_t* scratch, FrameCounters* counters);
+                           int32_t* scratch, FrameCounters* counters, unsigned* sticky);
 void launch_walk(hipStream_t s, const WalkParams& p, int tile_shape);
 
 }  // namespace c5

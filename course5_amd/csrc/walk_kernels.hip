@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void scan_sums_inplace(int32_t* __restrict__ s
 __global__ __launch_bounds__(256) void scan_finish(const int32_t* __restrict__ count, int64_t n,
                                                    const int32_t* __restrict__ sums,
                                                    int32_t* __restrict__ offs, int64_t n_blocks,
-                                                   FrameCounters* counters) {
+                                                   FrameCounters* counters, unsigned* sticky) {
     const int64_t base = (blockIdx.x * 256ll + threadIdx.x) * 4;
     int c[4];
     int v = 0;
@@ -373,17 +373,18 @@ __global__ __launch_bounds__(256) void scan_finish(const int32_t* __restrict__ c
         const int grand = sums[n_blocks];
         offs[n] = grand;
         if (counters) counters->entries = static_cast<unsigned long long>(grand);
+        if (sticky) atomicMax(sticky, static_cast<unsigned>(grand));  // largest entry total since the host last looked
     }
 }
 
 void launch_exclusive_scan(hipStream_t s, const int32_t* count, int32_t* offs, int64_t n,
-                           int32_t* scratch, FrameCounters* counters) {
+                           int32_t* scratch, FrameCounters* counters, unsigned* sticky) {
     if (n <= 0) return;
     const int64_t n_blocks = (n + 1023) / 1024;
     hipLaunchKernelGGL(scan_block_sums, dim3(static_cast<unsigned>(n_blocks)), dim3(256), 0, s, count, n, scratch);
     hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(256), 0, s, scratch, n_blocks);
     hipLaunchKernelGGL(scan_finish, dim3(static_cast<unsigned>(n_blocks)), dim3(256), 0, s, count, n, scratch,
-                       offs, n_blocks, counters);
+                       offs, n_blocks, counters, sticky);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -657,7 +658,10 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
         if (s_step) atomicAdd(&P.counters->steps, static_cast<unsigned long long>(s_step));
         if (s_cov) atomicAdd(&P.counters->covered, static_cast<unsigned long long>(s_cov));
         if (s_sol) atomicAdd(&P.counters->solid_pixels, static_cast<unsigned long long>(s_sol));
-        if (s_ovf) atomicAdd(&P.counters->walk_overflow, s_ovf);
+        if (s_ovf) {
+            atomicAdd(&P.counters->walk_overflow, s_ovf);
+            atomicAdd(P.sticky + 1, s_ovf);
+        }
     }
 }
 
@@ -880,7 +884,10 @@ __global__ __launch_bounds__(256) void walk_composite_lds(WalkParams P) {
         if (s_step) atomicAdd(&P.counters->steps, static_cast<unsigned long long>(s_step));
         if (s_cov) atomicAdd(&P.counters->covered, static_cast<unsigned long long>(s_cov));
         if (s_sol) atomicAdd(&P.counters->solid_pixels, static_cast<unsigned long long>(s_sol));
-        if (s_ovf) atomicAdd(&P.counters->walk_overflow, s_ovf);
+        if (s_ovf) {
+            atomicAdd(&P.counters->walk_overflow, s_ovf);
+            atomicAdd(P.sticky + 1, s_ovf);
+        }
     }
 }
 
