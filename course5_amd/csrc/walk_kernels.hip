@@ -582,8 +582,9 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
         } else {
             x = P.Xtab[col];
             y = P.Ytab[global_row_of(im, lrow)];
-            e0 = P.entry_offs[lp];
-            e1 = P.entry_offs[lp + 1];
+            // touched once per frame: keep them from displacing the cell records in L2 / Infinity Cache
+            e0 = __builtin_nontemporal_load(P.entry_offs + lp);
+            e1 = __builtin_nontemporal_load(P.entry_offs + lp + 1);
             if (e1 > e0) cell = next_entry<kUp>(P.entries, e0, e1, s_cur);
         }
     }
@@ -635,7 +636,8 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
             result.x = static_cast<float>(tau);  // plane.cpp:165
             result.y = static_cast<float>(I);    // plane.cpp:166
         }
-        P.out[lp] = result;
+        __builtin_nontemporal_store(result.x, &P.out[lp].x);
+        __builtin_nontemporal_store(result.y, &P.out[lp].y);
     }
 
     // segments per image row (load balancing of row blocks across GPUs): reduce over the lanes of a
@@ -743,8 +745,9 @@ __global__ __launch_bounds__(256) void walk_composite_lds(WalkParams P) {
         } else {
             x = P.Xtab[col];
             y = P.Ytab[global_row_of(im, lrow)];
-            e0 = P.entry_offs[lp];
-            e1 = P.entry_offs[lp + 1];
+            // touched once per frame: keep them from displacing the cell records in L2 / Infinity Cache
+            e0 = __builtin_nontemporal_load(P.entry_offs + lp);
+            e1 = __builtin_nontemporal_load(P.entry_offs + lp + 1);
             if (e1 > e0) nb = next_entry<kUp>(P.entries, e0, e1, s_cur);
         }
     }
@@ -865,7 +868,8 @@ __global__ __launch_bounds__(256) void walk_composite_lds(WalkParams P) {
             result.x = static_cast<float>(tau);  // plane.cpp:165
             result.y = static_cast<float>(I);    // plane.cpp:166
         }
-        P.out[lp] = result;
+        __builtin_nontemporal_store(result.x, &P.out[lp].x);
+        __builtin_nontemporal_store(result.y, &P.out[lp].y);
     }
 
     if (P.row_cost) {
