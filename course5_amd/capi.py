@@ -39,7 +39,8 @@ class Stats(C.Structure):
                 ("entries", C.c_int64), ("boundary_faces", C.c_int64), ("steps", C.c_int64),
                 ("walk_overflow", C.c_int32), ("entry_overflow", C.c_int32),
                 ("ms_transform", C.c_float), ("ms_records", C.c_float), ("ms_entries", C.c_float),
-                ("ms_solids", C.c_float), ("ms_walk", C.c_float), ("ms_total", C.c_float)]
+                ("ms_solids", C.c_float), ("ms_walk", C.c_float), ("ms_total", C.c_float),
+                ("odd_pixels", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

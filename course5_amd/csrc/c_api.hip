@@ -88,6 +88,9 @@ struct c5_context {
     FrameSlot slots[kFrameSlots];
     int64_t frame_index = 0;
     int last_slot = 0;
+    int algorithm = 0;        // 0: walk, 1: bin_sort_resolve
+    bool grid_conforming = true;
+    DeviceBuffer offs64, scratch64, segs;  // bin_sort_resolve
     int pipeline = 0;  // measured: overlapping the next setup with the walk is slower (1.43 vs 1.38 ms/frame)
     c5::RotationList view{};
     Solid solids[C5_MAX_SOLIDS];
@@ -214,6 +217,79 @@ int drain(c5_context* ctx) {
     return C5_OK;
 }
 
+// (a9) solid mask of this frame into fs.mask; returns whether any solid exists
+int enqueue_solids(c5_context* ctx, FrameSlot& fs, int slot_id, hipStream_t s, c5::SolidTable& table, bool& any_solid) {
+    const c5::ImageParams& im = ctx->im;
+    const int64_t n_px = static_cast<int64_t>(im.n_local_rows) * im.res_x;
+    const int64_t padded = ((n_px + 1023) / 1024) * 1024;
+    any_solid = false;
+    for (int k = 0; k < C5_MAX_SOLIDS; ++k) {
+        table.colour[k] = ctx->solids[k].colour;
+        if (ctx->solids[k].n_tets > 0) any_solid = true;
+    }
+    table.n_slots = C5_MAX_SOLIDS;
+    if (any_solid) {
+        C5_HIP(ctx, hipMemsetAsync(fs.mask.ptr, 0, static_cast<size_t>(padded) * sizeof(uint32_t), s));
+        for (int k = 0; k < C5_MAX_SOLIDS; ++k) {
+            Solid& so = ctx->solids[k];
+            if (so.n_tets <= 0) continue;
+            c5::launch_transform_aos(s, so.raw.as<double>(), so.view[slot_id].as<double>(), so.n_points, so.rots);
+            c5::launch_solid_mask_raster(s, so.view[slot_id].as<double>(), so.faces.as<int4>(), so.n_faces,
+                                         static_cast<uint32_t>(k) + 1u, ctx->ytab.as<double>(), im,
+                                         fs.mask.as<uint32_t>());
+        }
+    }
+    return C5_OK;
+}
+
+// bin_sort_resolve: the reference's algorithm (plane.cpp:184-192 + 144-172) on the GPU.  Needs the
+// segment total on the host between its two binning passes, so it synchronises.
+int enqueue_bin_sort(c5_context* ctx, FrameSlot& fs, const c5::GridView& g, int slot_id, float2* out_dev,
+                     hipStream_t s, hipStream_t main_s, bool timed) {
+    const c5::ImageParams& im = ctx->im;
+    const int64_t n_px = static_cast<int64_t>(im.n_local_rows) * im.res_x;
+    const int64_t padded = ((n_px + 1023) / 1024) * 1024;
+    auto mark = [&](int k, hipStream_t st) -> hipError_t { return timed ? hipEventRecord(fs.ev[k], st) : hipSuccess; };
+    C5_HIP(ctx, mark(2, s));
+    C5_HIP(ctx, ctx->offs64.ensure(static_cast<size_t>(padded + 1024) * sizeof(int64_t)));
+    C5_HIP(ctx, ctx->scratch64.ensure(static_cast<size_t>(padded / 1024 + 1024) * sizeof(int64_t)));
+    C5_HIP(ctx, hipMemsetAsync(fs.count.ptr, 0, static_cast<size_t>(padded + 1) * sizeof(int32_t), s));
+    unsigned* odd = &fs.counters.as<c5::FrameCounters>()->odd_pixels;
+    c5::launch_bin_count(s, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im, fs.count.as<int32_t>(), odd);
+    c5::launch_scan64(s, fs.count.as<int32_t>(), ctx->offs64.as<int64_t>(), n_px, ctx->scratch64.as<int64_t>());
+    int64_t total = 0;
+    C5_HIP(ctx, hipMemcpyAsync(&total, ctx->offs64.as<int64_t>() + n_px, sizeof total, hipMemcpyDeviceToHost, s));
+    C5_HIP(ctx, hipStreamSynchronize(s));
+    C5_HIP(ctx, ctx->segs.ensure(static_cast<size_t>(total + 16) * c5::segment_bytes()));
+    c5::launch_bin_fill(s, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im, fs.count.as<int32_t>(),
+                        ctx->offs64.as<int64_t>(), ctx->segs.ptr);
+    C5_HIP(ctx, mark(3, s));
+    c5::SolidTable table{};
+    bool any_solid = false;
+    int rc = enqueue_solids(ctx, fs, slot_id, s, table, any_solid);
+    if (rc) return rc;
+    C5_HIP(ctx, mark(4, s));
+    c5::launch_resolve(s, g, im, ctx->offs64.as<int64_t>(), ctx->segs.ptr, any_solid ? fs.mask.as<uint32_t>() : nullptr,
+                       table, ctx->alpha_limit, out_dev, fs.counters.as<c5::FrameCounters>());
+    C5_HIP(ctx, mark(5, s));
+    C5_HIP(ctx, hipGetLastError());
+    C5_HIP(ctx, hipMemcpyAsync(fs.host_counters, fs.counters.ptr, sizeof(c5::FrameCounters), hipMemcpyDeviceToHost, s));
+    C5_HIP(ctx, hipMemcpyAsync(ctx->host_sticky, ctx->sticky.ptr, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    C5_HIP(ctx, hipStreamSynchronize(s));
+    fs.host_counters->segments = static_cast<unsigned long long>(total);
+    if (ctx->pipeline) {  // keep the two-stream bookkeeping consistent
+        C5_HIP(ctx, hipEventRecord(fs.setup_done, s));
+        C5_HIP(ctx, hipStreamWaitEvent(main_s, fs.setup_done, 0));
+        C5_HIP(ctx, hipEventRecord(fs.walk_done, main_s));
+        fs.walk_recorded = true;
+    }
+    ctx->last_slot = slot_id;
+    ctx->frame_index += 1;
+    ctx->frame_pending = true;
+    ctx->frame_timed = timed;
+    return C5_OK;
+}
+
 // Enqueue one frame; the image goes to out_dev.  The per-view setup runs on the auxiliary stream
 // into frame slot (frame_index & 1), the walk on the main stream once that setup is done, so the
 // setup of the next frame overlaps this frame's walk.
@@ -276,6 +352,8 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     // (a2) view transform
     c5::launch_transform_soa(s, g.px, g.py, g.pz, g.vx, g.vy, g.vz, g.n_pts, ctx->view);
     C5_HIP(ctx, mark(1, s));
+    const bool bin_sort = ctx->algorithm == 1 || !ctx->grid_conforming;
+    if (bin_sort) return enqueue_bin_sort(ctx, fs, g, slot_id, out_dev, s, main_s, timed);
     // (a1, a10, a13 constants) per-cell records
     c5::launch_build_records(s, g, ctx->alpha_limit, ctx->order);
     C5_HIP(ctx, mark(2, s));
@@ -296,22 +374,8 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     // (a9) solids
     c5::SolidTable table{};
     bool any_solid = false;
-    for (int k = 0; k < C5_MAX_SOLIDS; ++k) {
-        table.colour[k] = ctx->solids[k].colour;
-        if (ctx->solids[k].n_tets > 0) any_solid = true;
-    }
-    table.n_slots = C5_MAX_SOLIDS;
-    if (any_solid) {
-        C5_HIP(ctx, hipMemsetAsync(fs.mask.ptr, 0, static_cast<size_t>(padded) * sizeof(uint32_t), s));
-        for (int k = 0; k < C5_MAX_SOLIDS; ++k) {
-            Solid& so = ctx->solids[k];
-            if (so.n_tets <= 0) continue;
-            c5::launch_transform_aos(s, so.raw.as<double>(), so.view[slot_id].as<double>(), so.n_points, so.rots);
-            c5::launch_solid_mask_raster(s, so.view[slot_id].as<double>(), so.faces.as<int4>(), so.n_faces,
-                                         static_cast<uint32_t>(k) + 1u, ctx->ytab.as<double>(), im,
-                                         fs.mask.as<uint32_t>());
-        }
-    }
+    rc = enqueue_solids(ctx, fs, slot_id, s, table, any_solid);
+    if (rc) return rc;
     C5_HIP(ctx, mark(4, s));
 
     // (a11-a14) walk on the main stream, after this slot's setup
@@ -389,6 +453,7 @@ int finish_frame(c5_context* ctx) {
     st.boundary_faces = ctx->n_bfaces;
     st.steps = static_cast<int64_t>(hc.steps);
     st.walk_overflow = static_cast<int32_t>(hc.walk_overflow);
+    st.odd_pixels = static_cast<int64_t>(hc.odd_pixels);
     if (ctx->frame_timed) {
         float* dst[5] = {&st.ms_transform, &st.ms_records, &st.ms_entries, &st.ms_solids, &st.ms_walk};
         for (int k = 0; k < 5; ++k) C5_HIP(ctx, hipEventElapsedTime(dst[k], fs.ev[k], fs.ev[k + 1]));
@@ -506,7 +571,8 @@ void c5_destroy(c5_context* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
     DeviceBuffer* bufs[] = {&ctx->px, &ctx->py, &ctx->pz, &ctx->cell_vert, &ctx->cell_adj, &ctx->alpha,
-                            &ctx->q, &ctx->bface, &ctx->xtab, &ctx->ytab, &ctx->out, &ctx->sticky};
+                            &ctx->q, &ctx->bface, &ctx->xtab, &ctx->ytab, &ctx->out, &ctx->sticky,
+                            &ctx->offs64, &ctx->scratch64, &ctx->segs};
     if (ctx->host_sticky) (void)hipHostFree(ctx->host_sticky);
     for (DeviceBuffer* b : bufs) b->release();
     for (FrameSlot& fs : ctx->slots) {
@@ -560,8 +626,14 @@ int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int3
     std::vector<int32_t> adj;
     std::vector<uint32_t> bfaces;
     std::string err;
-    if (!c5::build_face_adjacency(cell_vert, n_cells, n_pts, adj, bfaces, err))
-        return fail(ctx, err.find("range") != std::string::npos ? C5_ERR_INVALID : C5_ERR_MESH, "%s", err.c_str());
+    bool conforming = true;
+    if (!c5::build_face_adjacency(cell_vert, n_cells, n_pts, adj, bfaces, err)) {
+        if (err.find("range") != std::string::npos) return fail(ctx, C5_ERR_INVALID, "%s", err.c_str());
+        // a face shared by more than two cells: no walk possible, the reference's own algorithm will do
+        conforming = false;
+        adj.assign(static_cast<size_t>(4 * n_cells), -1);
+        bfaces.clear();
+    }
 
     // SoA split of the points
     std::vector<double> sx(static_cast<size_t>(n_pts)), sy(static_cast<size_t>(n_pts)), sz(static_cast<size_t>(n_pts));
@@ -608,6 +680,7 @@ int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int3
     ctx->n_pts = n_pts;
     ctx->n_cells = n_cells;
     ctx->n_bfaces = static_cast<int64_t>(bfaces.size());
+    ctx->grid_conforming = conforming;
     return C5_OK;
 }
 
@@ -788,6 +861,9 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
         if (ctx->n_cells > 0 || ctx->have_image)
             return fail(ctx, C5_ERR_STATE, "set \"pipeline\" before uploading the grid and setting the image");
         ctx->pipeline = static_cast<int>(value) != 0;
+    } else if (n == "algorithm") {
+        if (value != 0 && value != 1) return fail(ctx, C5_ERR_INVALID, "algorithm must be 0 (walk) or 1 (bin_sort_resolve)");
+        ctx->algorithm = static_cast<int>(value);
     } else if (n == "lds_stage") {
         ctx->lds_stage = static_cast<int>(value) != 0;
     } else if (n == "integration") {

@@ -92,6 +92,8 @@ struct FrameCounters {
     unsigned long long entries;
     unsigned int walk_overflow;
     unsigned int entry_overflow;
+    unsigned int odd_pixels;  // bin_sort_resolve: (pixel, cell) pairs with an odd number of covering faces
+    unsigned int pad;
 };
 
 // global row -> local row of this rank, or -1

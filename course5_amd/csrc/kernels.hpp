@@ -54,6 +54,17 @@ void launch_transform_aos(hipStream_t s, const double* in, double* out, int64_t 
 void launch_solid_mask_raster(hipStream_t s, const double* pts, const int4* faces, int64_t n_faces,
                               uint32_t value, const double* Ytab, const ImageParams& im, uint32_t* mask);
 
+// bin-sort-resolve (exact_kernels.hip): the reference's algorithm on the GPU
+void launch_bin_count(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
+                      const ImageParams& im, int32_t* count, unsigned* odd_pixels);
+void launch_bin_fill(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
+                     const ImageParams& im, int32_t* count, const int64_t* offs, void* segs);
+void launch_scan64(hipStream_t s, const int32_t* count, int64_t* offs, int64_t n, int64_t* scratch);
+void launch_resolve(hipStream_t s, const GridView& g, const ImageParams& im, const int64_t* offs, void* segs,
+                    const uint32_t* mask, const SolidTable& solids, double alpha_limit, float2* out,
+                    FrameCounters* counters);
+size_t segment_bytes();
+
 // walk_kernels.hip
 void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, int order);
 void launch_entry_count(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,

@@ -38,7 +38,7 @@ enum {
     C5_ERR_INVALID = 1,     /* bad argument (null pointer, size, id range) */
     C5_ERR_STATE = 2,       /* call order: render before grid/image were set */
     C5_ERR_HIP = 3,         /* HIP runtime failure (message carries hipGetErrorString) */
-    C5_ERR_MESH = 4,        /* non-conforming grid: a face shared by more than two cells */
+    C5_ERR_MESH = 4,        /* c5_face_adjacency: a face is shared by more than two cells */
     C5_ERR_NO_DEVICE = 5,   /* no usable GPU */
     C5_ERR_WALK = 6,        /* a ray exceeded the step bound (malformed grid) */
     C5_RETRY = 7            /* c5_synchronize: an internal buffer was too small and has been
@@ -78,6 +78,9 @@ typedef struct c5_stats {
     float ms_solids;         /* solid mask raster                  (a6, a9) */
     float ms_walk;           /* walk_composite                     (a11-a14) */
     float ms_total;          /* first kernel start -> image complete in HBM */
+    int64_t odd_pixels;      /* bin_sort_resolve only: (pixel, cell) pairs covered by an odd number of the
+                                cell's faces, i.e. exactly degenerate alignment; the reference mis-pairs or
+                                aborts there (plane.cpp:39-41, line.cpp:40-47), here they are skipped */
 } c5_stats;
 
 /* --- lifetime ----------------------------------------------------------------------------- */
@@ -98,7 +101,8 @@ int c5_set_stream(c5_context* ctx, void* hip_stream);
  * and the tetra AoS (tetra.hpp:12-46).  xyz[n_pts][3] raw (untransformed) points,
  * cell_vert[n_cells][4] point ids, alpha/q[n_cells] = AbsorpCoef / radEnLooseRate
  * (object3d_accretion_disk.cpp:4).  Builds face adjacency; n_cells must be < 2^28
- * (line.hpp:71-79). */
+ * (line.hpp:71-79).  A grid in which some face belongs to more than two cells cannot be walked:
+ * it is accepted and rendered with "algorithm" 1 (see c5_set_option). */
 int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int32_t* cell_vert,
                    int64_t n_cells, const double* alpha, const double* q);
 /* Replace only the cell scalars of the uploaded grid. */
@@ -138,6 +142,12 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  once the transmittance T falls below "transmittance_cutoff" (default 1e-12,
  *                  0 disables).  Both agree to rounding wherever the reference's recurrence is
  *                  well conditioned (it is not for DBL_EPSILON <= alpha < ~1e-8).
+ *   "algorithm"    0 (default for conforming grids): face-adjacency walk.  1: bin_sort_resolve, the
+ *                  reference's own algorithm on the GPU (every face of every cell scan-converted onto
+ *                  the pixels, per-pixel sort by z, integrate) — handles tet soups, overlapping and
+ *                  non-conforming cells like the reference does; c5_upload_grid selects it by itself
+ *                  when a face is shared by more than two cells.  Needs ~24 B per ray-cell segment
+ *                  and synchronises inside c5_render_device.
  *   "lds_stage"    1 (default): walk_composite_lds — per step a wavefront loads each distinct cell
  *                  record once and stages it through LDS; 0: every lane loads its own record.
  *   "tile"         wavefront tile: 0 = 64x1 row tile, 1 = 16x4, 2 = 8x8 pixels.

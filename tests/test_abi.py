@@ -39,7 +39,7 @@ def test_status_codes_match_header():
 
 def test_struct_layouts():
     assert ctypes.sizeof(capi.Rotation) == 24
-    assert ctypes.sizeof(capi.Stats) == 6 * 8 + 2 * 4 + 6 * 4
+    assert ctypes.sizeof(capi.Stats) == 6 * 8 + 2 * 4 + 6 * 4 + 8
 
 
 def test_face_adjacency_helper_runs_without_a_gpu():
@@ -57,7 +57,7 @@ def test_face_adjacency_helper_runs_without_a_gpu():
     assert len(set(cells[a]) & set(cells[b])) == 3
 
 
-def test_non_conforming_grid_is_rejected():
+def test_non_conforming_grid_is_reported_by_the_adjacency_helper():
     xyz, cells = mg.cube8()
     dup = np.vstack([cells, cells[:1], cells[:1]])  # the same cell three times -> faces shared by 3 cells
     with pytest.raises(capi.C5Error) as e:
