@@ -683,7 +683,7 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
 // The global loads of step k+1 are issued as soon as the exit face of step k is known and are in
 // flight during step k's exp/divide work, as in the direct kernel.
 // ------------------------------------------------------------------------------------------
-constexpr int kStageSlots = 24;   // runs of equal cell ids staged per wavefront and step (more: direct loads)
+constexpr int kStageSlots = 32;   // runs of equal cell ids staged per wavefront and step (more: direct loads)
 constexpr int kRecStride = 9;     // CellRecord stride in LDS, 16-byte units (128 B + 16 B pad)
 using V2 = double __attribute__((ext_vector_type(2)));  // 16 bytes as one SSA value (never an alloca)
 __device__ __forceinline__ D2 as_d2(V2 v) { return D2{v.x, v.y}; }
@@ -770,19 +770,23 @@ __global__ __launch_bounds__(256) void walk_composite_lds(WalkParams P) {
         // lane s learns the cell id of slot s (forward permute from the run heads)
         const int id_of_lane = __builtin_amdgcn_ds_permute((head ? slot : 63) << 2, head ? nb : -1);
         // 2. cooperative loads into registers: record pieces (8 lanes per slot, 8 slots per pass)
-        // Three passes of 8 slots (8 lanes x 16 B per record) + one pass for the optics (2 lanes per
+        // kPasses passes of 8 slots (8 lanes x 16 B per record) + one pass for the optics (2 lanes per
         // slot).  Lanes beyond the staged slots re-load slot 0's piece (same cache line, free) so that
-        // the loads are unconditional and the values stay in registers.  (40 slots with conditional
-        // passes measured slower: 1.52 vs 1.32 ms on the C3 frame.)
-        static_assert(kStageSlots == 24, "three record passes are written out below");
+        // the loads are unconditional and the values stay in registers.  Measured on the C3 frame
+        // (same GPU): 24 slots 1.31 ms, 32 slots 1.24 ms, 40 slots 1.38 ms and 48 slots 1.31 ms
+        // (registers: occupancy drops to 3 wavefronts per SIMD); a second staging round instead of the
+        // direct-load fallback 1.41 ms.
+        static_assert(kStageSlots % 8 == 0 && kStageSlots <= 32, "whole passes of 8 slots, one optics pass");
+        constexpr int kPasses = kStageSlots / 8;
         const int piece = lane & 7, sub = lane >> 3, so = lane >> 1;
-        const int id0 = __builtin_amdgcn_ds_bpermute((sub < n_staged ? sub : 0) << 2, id_of_lane);
-        const int id1 = __builtin_amdgcn_ds_bpermute((sub + 8 < n_staged ? sub + 8 : 0) << 2, id_of_lane);
-        const int id2 = __builtin_amdgcn_ds_bpermute((sub + 16 < n_staged ? sub + 16 : 0) << 2, id_of_lane);
+        V2 stage_r[kPasses];
+#pragma unroll
+        for (int pass = 0; pass < kPasses; ++pass) {  // fully unrolled: stage_r[] stays in registers
+            const int s_ = 8 * pass + sub;
+            const int id_ = __builtin_amdgcn_ds_bpermute((s_ < n_staged ? s_ : 0) << 2, id_of_lane);
+            stage_r[pass] = reinterpret_cast<const V2*>(P.rec + id_)[piece];
+        }
         const int ido = __builtin_amdgcn_ds_bpermute((so < n_staged ? so : 0) << 2, id_of_lane);
-        const V2 stage_r0 = reinterpret_cast<const V2*>(P.rec + id0)[piece];
-        const V2 stage_r1 = reinterpret_cast<const V2*>(P.rec + id1)[piece];
-        const V2 stage_r2 = reinterpret_cast<const V2*>(P.rec + id2)[piece];
         const V2 stage_o0 = reinterpret_cast<const V2*>(P.opt + ido)[lane & 1];
 
         // ... while they are in flight: emission/absorption of the step just taken
@@ -801,9 +805,9 @@ __global__ __launch_bounds__(256) void walk_composite_lds(WalkParams P) {
 
         // 3. park the pieces in LDS (the previous step's reads are long done: same wavefront, in order)
         __builtin_amdgcn_wave_barrier();
-        if (sub < n_staged) my_rec[sub * kRecStride + piece] = stage_r0;
-        if (sub + 8 < n_staged) my_rec[(sub + 8) * kRecStride + piece] = stage_r1;
-        if (sub + 16 < n_staged) my_rec[(sub + 16) * kRecStride + piece] = stage_r2;
+#pragma unroll
+        for (int pass = 0; pass < kPasses; ++pass)
+            if (8 * pass + sub < n_staged) my_rec[(8 * pass + sub) * kRecStride + piece] = stage_r[pass];
         if (so < n_staged) my_opt[lane] = stage_o0;
         __builtin_amdgcn_wave_barrier();
 
