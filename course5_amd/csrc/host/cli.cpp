@@ -36,6 +36,9 @@ const option_spec kOptions[] = {
     {"device", 0, true, "GPU ordinal", "0"},
     {"no_solids", 0, false, "do not generate the Roche lobe and the accretor sphere", nullptr},
     {"stats", 0, false, "print per-stage GPU timings and segment counts", nullptr},
+    {"raw_vti", 0, false, "write the .vti uncompressed (default: zlib blocks, like vtkXMLImageDataWriter)", nullptr},
+    {"reference_algorithm", 0, false, "bin + sort + resolve on the GPU (for grids with overlapping cells)", nullptr},
+    {"selftest_vti", 0, true, "write a synthetic 48x32 image to this .vti and exit (checks the writer, no GPU)", nullptr},
     {"parse_only", 0, false, "read the input and generate the solids, print sizes, no GPU work", nullptr},
     {"dump_solids", 0, true, "write generated solid tets to this file (int64 count + doubles per object)", nullptr},
     {"frames", 0, true, "number of frames of a sweep (grid stays on the GPU)", "1"},
@@ -116,6 +119,9 @@ bool program_options(int argc, char** argv, std::ostream& out) {
         else if (n == "device") cfg.device = static_cast<int>(to_integer(n, v));
         else if (n == "no_solids") cfg.no_solids = true;
         else if (n == "stats") cfg.print_stats = true;
+        else if (n == "raw_vti") cfg.raw_vti = true;
+        else if (n == "reference_algorithm") cfg.reference_algorithm = true;
+        else if (n == "selftest_vti") cfg.selftest_vti = v;
         else if (n == "parse_only") cfg.parse_only = true;
         else if (n == "dump_solids") cfg.dump_solids = v;
         else if (n == "frames") cfg.frames = static_cast<std::size_t>(std::max(1ll, to_integer(n, v)));
@@ -161,6 +167,7 @@ bool program_options(int argc, char** argv, std::ostream& out) {
         print_usage(out);
         return false;
     }
+    if (!cfg.selftest_vti.empty()) return true;
     if (!(have_file && have_dest)) {  // main.cpp:43-51
         out << "Error! Source filename and destination filename must be specified" << std::endl;
         print_usage(out);

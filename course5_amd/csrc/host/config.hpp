@@ -25,6 +25,9 @@ struct render_config {
     bool no_solids = false;
     bool print_stats = false;
     bool parse_only = false;      // read the input, generate the solids, report sizes, no GPU work
+    bool raw_vti = false;         // write uncompressed appended data instead of zlib blocks
+    bool reference_algorithm = false;  // force the bin-sort-resolve path (tet soups with overlapping cells)
+    std::string selftest_vti;     // write a small synthetic image with the configured encoding and exit (no GPU)
     std::string dump_solids;      // write the generated solid tets (raw doubles) for inspection
     std::size_t frames = 1;       // > 1: sweep, grid stays resident on the GPU
     std::string sweep = "Y";      // which angle advances per frame: X, Y, D or I

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <memory>
 #include <iostream>
+#include <limits>
 #include <stdexcept>
 #include <thread>
 
@@ -32,6 +33,19 @@ std::string frame_name(const std::string& destination, std::size_t k, std::size_
 int main(int argc, char** argv) try {
     const render_config& config = app::instance().config;
     if (!program_options(argc, argv, std::cout)) return 0;  // main.cpp:74-78
+
+    if (!config.selftest_vti.empty()) {  // writer check without a GPU: value = x + 100 y (+0.5 on ch1), one NaN pixel
+        const int w = 48, h = 32;
+        std::vector<float> px(static_cast<size_t>(w) * h * 2);
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                px[(static_cast<size_t>(y) * w + x) * 2] = static_cast<float>(x + 100 * y);
+                px[(static_cast<size_t>(y) * w + x) * 2 + 1] = static_cast<float>(x + 100 * y) + 0.5f;
+            }
+        px[(5 * w + 7) * 2] = px[(5 * w + 7) * 2 + 1] = std::numeric_limits<float>::quiet_NaN();
+        object2d(px, w, h).export_to_vti(config.selftest_vti);
+        return 0;
+    }
 
     const std::vector<double> domain(DOMAIN_BOUNDS, DOMAIN_BOUNDS + 4);  // main.cpp:83
 

@@ -7,7 +7,8 @@
 #include "vtk_io.hpp"
 
 void object2d::export_to_vti(const std::string& filename) const {
-    write_vti(filename, _pixels.data(), static_cast<int>(_res_x), static_cast<int>(_res_y));
+    write_vti(filename, _pixels.data(), static_cast<int>(_res_x), static_cast<int>(_res_y),
+              !app::instance().config.raw_vti);
 }
 
 void plane::check(int rc, const char* what) {
@@ -57,6 +58,7 @@ plane::plane(std::size_t res_x, std::size_t res_y, std::vector<object3d_base> ob
               "c5_upload_grid");
     check(c5_set_image(_ctx, static_cast<int>(res_x), static_cast<int>(res_y), global_boundaries.data()), "c5_set_image");
     check(c5_set_alpha_limit(_ctx, app::instance().config.limit_alpha_value), "c5_set_alpha_limit");  // line.cpp:204
+    if (app::instance().config.reference_algorithm) check(c5_set_option(_ctx, "algorithm", 1.0), "c5_set_option");
     update_views(objects3d);
     if (hipMalloc(&_device_image, res_x * res_y * 2 * sizeof(float)) != hipSuccess)
         throw std::runtime_error("hipMalloc of the output image failed");

@@ -9,6 +9,8 @@
 #include <sstream>
 #include <stdexcept>
 
+#include <zlib.h>
+
 namespace {
 
 std::string lower(std::string s) {
@@ -269,13 +271,45 @@ vtk_grid read_legacy_vtk(const std::string& path) {
     return g;
 }
 
-void write_vti(const std::string& path, const float* image, int res_x, int res_y) {
+namespace {
+
+std::string base64(const unsigned char* data, size_t n) {
+    static const char tab[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    std::string out;
+    out.reserve((n + 2) / 3 * 4);
+    size_t i = 0;
+    for (; i + 2 < n; i += 3) {
+        const unsigned v = (data[i] << 16) | (data[i + 1] << 8) | data[i + 2];
+        out.push_back(tab[(v >> 18) & 63]);
+        out.push_back(tab[(v >> 12) & 63]);
+        out.push_back(tab[(v >> 6) & 63]);
+        out.push_back(tab[v & 63]);
+    }
+    if (i + 1 == n) {
+        const unsigned v = data[i] << 16;
+        out.push_back(tab[(v >> 18) & 63]);
+        out.push_back(tab[(v >> 12) & 63]);
+        out += "==";
+    } else if (i + 2 == n) {
+        const unsigned v = (data[i] << 16) | (data[i + 1] << 8);
+        out.push_back(tab[(v >> 18) & 63]);
+        out.push_back(tab[(v >> 12) & 63]);
+        out.push_back(tab[(v >> 6) & 63]);
+        out.push_back('=');
+    }
+    return out;
+}
+
+}  // namespace
+
+void write_vti(const std::string& path, const float* image, int res_x, int res_y, bool compressed) {
     std::ofstream f(path, std::ios::binary);
     if (!f) throw std::runtime_error("cannot write '" + path + "'");
     const uint64_t n_values = static_cast<uint64_t>(res_x) * static_cast<uint64_t>(res_y) * 2u;
     const uint64_t n_bytes = n_values * sizeof(double);
     f << "<?xml version=\"1.0\"?>\n"
-      << "<VTKFile type=\"ImageData\" version=\"1.0\" byte_order=\"LittleEndian\" header_type=\"UInt64\">\n"
+      << "<VTKFile type=\"ImageData\" version=\"1.0\" byte_order=\"LittleEndian\" header_type=\"UInt64\""
+      << (compressed ? " compressor=\"vtkZLibDataCompressor\"" : "") << ">\n"
       << "  <ImageData WholeExtent=\"0 " << res_x - 1 << " 0 " << res_y - 1 << " 0 0\" Origin=\"0 0 0\" Spacing=\"1 1 1\">\n"
       << "    <Piece Extent=\"0 " << res_x - 1 << " 0 " << res_y - 1 << " 0 0\">\n"
       << "      <PointData Scalars=\"ImageScalars\">\n"
@@ -284,14 +318,49 @@ void write_vti(const std::string& path, const float* image, int res_x, int res_y
       << "      <CellData/>\n"
       << "    </Piece>\n"
       << "  </ImageData>\n"
-      << "  <AppendedData encoding=\"raw\">\n   _";
-    f.write(reinterpret_cast<const char*>(&n_bytes), sizeof n_bytes);
+      << "  <AppendedData encoding=\"" << (compressed ? "base64" : "raw") << "\">\n   _";
     // fp32 results widened to the VTK_DOUBLE the reference allocates (object2d.cpp:13,17-21)
-    std::vector<double> row(static_cast<size_t>(res_x) * 2);
-    for (int y = 0; y < res_y; ++y) {
-        const float* src = image + static_cast<size_t>(y) * res_x * 2;
-        for (size_t k = 0; k < row.size(); ++k) row[k] = static_cast<double>(src[k]);
-        f.write(reinterpret_cast<const char*>(row.data()), static_cast<std::streamsize>(row.size() * sizeof(double)));
+    if (!compressed) {
+        f.write(reinterpret_cast<const char*>(&n_bytes), sizeof n_bytes);
+        std::vector<double> row(static_cast<size_t>(res_x) * 2);
+        for (int y = 0; y < res_y; ++y) {
+            const float* src = image + static_cast<size_t>(y) * res_x * 2;
+            for (size_t k = 0; k < row.size(); ++k) row[k] = static_cast<double>(src[k]);
+            f.write(reinterpret_cast<const char*>(row.data()), static_cast<std::streamsize>(row.size() * sizeof(double)));
+        }
+    } else {
+        // vtkZLibDataCompressor layout: header {#blocks, block size, size of the last block (0 = full),
+        // compressed size of each block} as header_type words, base64-encoded on its own, followed by
+        // the concatenated deflated blocks, base64-encoded as one stream.
+        constexpr uint64_t kBlock = 32768;
+        const uint64_t n_blocks = (n_bytes + kBlock - 1) / kBlock;
+        std::vector<uint64_t> header(3 + n_blocks);
+        header[0] = n_blocks;
+        header[1] = kBlock;
+        header[2] = n_bytes % kBlock;
+        std::vector<std::vector<unsigned char>> packed(n_blocks);
+        const int64_t nb = static_cast<int64_t>(n_blocks);
+#pragma omp parallel for schedule(dynamic, 16)
+        for (int64_t b = 0; b < nb; ++b) {
+            const uint64_t first = static_cast<uint64_t>(b) * kBlock / sizeof(double);
+            const uint64_t count = std::min<uint64_t>(kBlock / sizeof(double), n_values - first);
+            double vals[kBlock / sizeof(double)];
+            for (uint64_t k = 0; k < count; ++k) vals[k] = static_cast<double>(image[first + k]);
+            uLongf cap = compressBound(static_cast<uLong>(count * sizeof(double)));
+            packed[static_cast<size_t>(b)].resize(cap);
+            if (compress2(packed[static_cast<size_t>(b)].data(), &cap, reinterpret_cast<const Bytef*>(vals),
+                          static_cast<uLong>(count * sizeof(double)), Z_DEFAULT_COMPRESSION) != Z_OK)
+                cap = 0;
+            packed[static_cast<size_t>(b)].resize(cap);
+        }
+        std::vector<unsigned char> body;
+        for (uint64_t b = 0; b < n_blocks; ++b) {
+            if (packed[b].empty()) throw std::runtime_error("zlib failed while writing '" + path + "'");
+            header[3 + b] = packed[b].size();
+            body.insert(body.end(), packed[b].begin(), packed[b].end());
+        }
+        f << base64(reinterpret_cast<const unsigned char*>(header.data()), header.size() * sizeof(uint64_t));
+        f << base64(body.data(), body.size());
     }
     f << "\n  </AppendedData>\n</VTKFile>\n";
     if (!f) throw std::runtime_error("error while writing '" + path + "'");

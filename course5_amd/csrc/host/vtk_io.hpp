@@ -25,4 +25,7 @@ vtk_grid read_legacy_vtk(const std::string& path);
 
 // image[row][col][2] fp32 (col fastest) -> .vti with dims (res_x, res_y, 1), origin 0, spacing 1,
 // Float64 x 2 "ImageScalars" (object2d.cpp:12-13).
-void write_vti(const std::string& path, const float* image, int res_x, int res_y);
+//   compressed = true : appended base64 data, vtkZLibDataCompressor blocks of 32 KiB — the encoding
+//                       vtkXMLImageDataWriter uses by default, i.e. what the reference writes;
+//   compressed = false: appended raw data (larger, fastest to write).
+void write_vti(const std::string& path, const float* image, int res_x, int res_y, bool compressed = true);

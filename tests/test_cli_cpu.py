@@ -122,3 +122,22 @@ def test_input_errors_are_reported(tmp_path):
     p.write_text(p.read_text().replace("radEnLooseRate", "somethingElse"))
     r = run("-f", str(p), "-d", str(tmp_path / "o.vti"), "--parse_only", "--no_solids")
     assert r.returncode == 1 and "radEnLooseRate" in r.stderr
+
+
+@pytest.mark.parametrize("raw", [False, True], ids=["zlib-blocks", "raw-appended"])
+def test_vti_writer_round_trip(tmp_path, raw):
+    """Both encodings of the .vti writer decode to the same Float64 x 2 "ImageScalars" image
+    (object2d.cpp:12-21); the default is vtkZLibDataCompressor blocks like vtkXMLImageDataWriter."""
+    from course5_amd import vtkio
+    out = tmp_path / "t.vti"
+    r = run("--selftest_vti", str(out), *( ["--raw_vti"] if raw else []))
+    assert r.returncode == 0, r.stderr
+    img, info = vtkio.read_vti(str(out))
+    assert info["name"] == "ImageScalars" and info["type"] == "Float64" and info["components"] == 2
+    assert info["dims"] == (48, 32, 1) and info["origin"] == "0 0 0" and info["spacing"] == "1 1 1"
+    yy, xx = np.mgrid[0:32, 0:48]
+    want = np.stack([xx + 100.0 * yy, xx + 100.0 * yy + 0.5], axis=-1)
+    want[5, 7] = np.nan
+    assert np.array_equal(img, want, equal_nan=True)
+    head = out.read_bytes()[:600].decode(errors="replace")
+    assert ("vtkZLibDataCompressor" in head) == (not raw)
