@@ -620,6 +620,8 @@ int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int3
     if (n_cells >= static_cast<int64_t>(c5::kNoCell))
         return fail(ctx, C5_ERR_INVALID, "cell count %lld does not fit 28 bits (line.hpp:71-79)",
                     static_cast<long long>(n_cells));
+    for (int64_t i = 0; i < 3 * n_pts; ++i)
+        if (!std::isfinite(xyz[i])) return fail(ctx, C5_ERR_INVALID, "point %lld has a non-finite coordinate", static_cast<long long>(i / 3));
     int rc = bind_device(ctx);
     if (rc) return rc;
 

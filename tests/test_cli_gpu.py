@@ -73,3 +73,34 @@ def test_course_sweep_keeps_the_grid_resident(tmp_path, oracle_port):
             ay += 0.05
         ref = oracle_port.render(xyz, cells, a, q32, mg.view_rotations(0.1, ay), 200, 150, mg.REFERENCE_BOUNDS)
         assert_images_match(img.astype(np.float32), ref["image"], f"frame {k}")
+
+
+def test_course_donor_sweep_moves_only_the_lobe(tmp_path, oracle_port):
+    """BASELINE config 5 in small: -D sweep with the grid and both solids resident on the GPU.  -D only
+    turns the Roche lobe (main.cpp:110, object3d_roche_lobe.cpp:48): the volume image is the same in
+    every frame, the NaN mask moves, and every frame matches the oracle fed the rotated lobe."""
+    xyz, cells, a, q = mg.workload("c1")
+    src, dst, dump = tmp_path / "c1.vtk", tmp_path / "d.vti", tmp_path / "solids.bin"
+    mg.write_vtk_ascii(str(src), xyz, cells, a, q)
+    rx, ry, step = 400, 300, 0.25
+    r = subprocess.run([COURSE, "-f", str(src), "-d", str(dst), "-x", str(rx), "-y", str(ry), "-X", "0.1", "-Y", "0.07",
+                        "--frames", "3", "--sweep", "D", "--sweep_step", str(step), "--dump_solids", str(dump)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    rots = mg.view_rotations(0.1, 0.07)
+    lobe, sphere = load_solids(str(dump))
+    masks = []
+    for k in range(3):
+        img, _ = vtkio.read_vti(str(tmp_path / f"d_{k:05d}.vti"))
+        donor = 0.0
+        for _ in range(k):
+            donor += step
+        lobe_view = oracle_port.rotate_points(lobe.reshape(-1, 3), np.vstack([[1.0, donor * PI, 1.0], rots])).reshape(-1, 12)
+        ref = oracle_port.render(xyz, cells, a, q, rots, rx, ry, mg.REFERENCE_BOUNDS,
+                                 solid_tets=np.vstack([lobe_view, sphere.reshape(-1, 12)]), solid_colour=float("nan"),
+                                 threads=8)
+        got = img.astype(np.float32)
+        assert np.array_equal(np.isnan(got), np.isnan(ref["image"])), k
+        assert_images_match(got, ref["image"], f"donor frame {k}")
+        masks.append(np.isnan(got[..., 0]))
+    assert not np.array_equal(masks[0], masks[1]) and not np.array_equal(masks[1], masks[2])
