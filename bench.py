@@ -54,6 +54,7 @@ def parse():
     p.add_argument("--tile", type=int, default=-1, help="wavefront tile shape override (0: 64x1, 1: 16x4, 2: 8x8)")
     p.add_argument("--lds-stage", type=int, default=-1, help="override: 1 = LDS-staged walk kernel, 0 = direct loads")
     p.add_argument("--pipeline", type=int, default=-1, help="override: overlap the next frame's setup with the walk (1) or not (0)")
+    p.add_argument("--overlap-setup", type=int, default=-1, help="override: entry lists beside build_records (1) or serial (0)")
     p.add_argument("--own-stream", action="store_true", help="run on the context's own (high priority) stream")
     p.add_argument("--backend", default="nccl", help="nccl (= RCCL, default); gloo only to rehearse N > 1 on one GPU")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -140,6 +141,8 @@ def main():
         ctx.set_option("tile", args.tile)
     if args.lds_stage >= 0:
         ctx.set_option("lds_stage", args.lds_stage)
+    if args.overlap_setup >= 0:
+        ctx.set_option("overlap_setup", args.overlap_setup)
     if not args.own_stream:
         ctx.set_stream(stream.cuda_stream)
 

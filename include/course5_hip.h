@@ -152,6 +152,8 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  record once and stages it through LDS; 0: every lane loads its own record.
  *   "tile"         wavefront tile: 0 = 64x1 row tile, 1 = 16x4, 2 = 8x8 pixels.
  *   "xcd_mode"     1 (default): 32-row bands dealt round-robin to the 8 XCDs; 0: row-major tiles.
+ *   "overlap_setup" 1: entry lists and solid mask are built on a side stream while build_records
+ *                  runs (only when "stage_timing" is 0).  Default 0: measured no faster.
  *   "pipeline"     1: two frame slots; the per-view setup of frame k + 1 runs on a second stream while
  *                  frame k is walked (set before c5_upload_grid / c5_set_image).  Default 0: on
  *                  MI355X the walk already fills the GPU and the overlap measured slower.
