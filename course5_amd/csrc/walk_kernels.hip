@@ -415,6 +415,41 @@ struct alignas(16) D2 {
     double a, b;
 };
 
+// exp(x) for x <= 0 (x = -alpha * dz).  Same scheme as the device library's exp — k = rint(x log2 e),
+// r = x - k ln 2 in two pieces, polynomial in r, scale by 2^k — but written as one fused
+// multiply-add per coefficient with the coefficients as scalar constants: the library version keeps
+// its eleven coefficients in vector registers (20 VGPRs of this kernel's 128) and pays a register
+// copy per Horner step.  Taylor coefficients to r^13: truncation 4e-18 for |r| <= ln2 / 2, result
+// within ~1 ulp.  Underflows to 0 below -745 like exp().
+__device__ __forceinline__ double exp_nonpositive(double x) {
+#pragma clang fp contract(fast)
+    const double k = rint(x * 1.4426950408889634074);  // log2(e)
+    double r = fma(k, -6.93147180369123816490e-01, x);  // ln2 high part (exact product for |k| < 2^10)
+    r = fma(k, -1.90821492927058770002e-10, r);         // ln2 low part
+    // p = p * r + c with c in a scalar register pair: hipcc on its own keeps every coefficient in a
+    // vector register pair and emits v_mov_b64 + v_fmac_f64 per step
+    auto step = [](double acc, double rr, double c) {
+        double out;
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(out) : "v"(acc), "v"(rr), "s"(c));
+        return out;
+    };
+    double p = step(1.0 / 6227020800.0, r, 1.0 / 479001600.0);  // 1/13! r + 1/12!
+    p = step(p, r, 1.0 / 39916800.0);
+    p = step(p, r, 1.0 / 3628800.0);
+    p = step(p, r, 1.0 / 362880.0);
+    p = step(p, r, 1.0 / 40320.0);
+    p = step(p, r, 1.0 / 5040.0);
+    p = step(p, r, 1.0 / 720.0);
+    p = step(p, r, 1.0 / 120.0);
+    p = step(p, r, 1.0 / 24.0);
+    p = step(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double y = ldexp(p, static_cast<int>(k));
+    return (x < -745.2) ? 0.0 : y;
+}
+
 // One emission/absorption step in the reference's own arithmetic (line.cpp:220-224):
 //   C = Q - alpha * I;   I = (Q - C * exp(-alpha * dz)) / alpha
 // with every product and sum rounded separately (no FMA contraction), so that the recurrence —
@@ -425,7 +460,7 @@ __device__ __forceinline__ double reference_emission_step(double I, double alpha
 #pragma clang fp contract(off)
     const double C = q - alpha_c * I;
     const double arg = -alpha_c * dz;
-    const double e = exp(arg);
+    const double e = exp_nonpositive(arg);
     return (q - C * e) * inv_alpha;
 }
 
@@ -622,7 +657,7 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
                 if (cur.o0.b != 0.0) I = reference_emission_step(I, cur.o0.b, cur.o1.b, cur.o1.a, sg.dz);
             } else if (T >= P.t_cutoff) {
                 // I = sum_k T_k (Q/alpha)(1 - e^{-alpha dz}); T_{k+1} = T_k e^{-alpha dz}
-                const double ex = exp(-cur.o0.b * sg.dz);
+                const double ex = exp_nonpositive(-cur.o0.b * sg.dz);
                 I = fma(T * cur.o1.a, 1.0 - ex, I);
                 T *= ex;
             }
@@ -796,7 +831,7 @@ __global__ __launch_bounds__(256) void walk_composite_lds(WalkParams P) {
             if (ORDER == 0) {
                 if (pend_a != 0.0) I = reference_emission_step(I, pend_a, pend_q, pend_aux, pend_dz);  // line.cpp:220-224
             } else if (T >= P.t_cutoff) {
-                const double ex = exp(-pend_a * pend_dz);
+                const double ex = exp_nonpositive(-pend_a * pend_dz);
                 I = fma(T * pend_aux, 1.0 - ex, I);
                 T *= ex;
             }
@@ -861,7 +896,7 @@ __global__ __launch_bounds__(256) void walk_composite_lds(WalkParams P) {
         if (ORDER == 0) {
             if (pend_a != 0.0) I = reference_emission_step(I, pend_a, pend_q, pend_aux, pend_dz);
         } else if (T >= P.t_cutoff) {
-            const double ex = exp(-pend_a * pend_dz);
+            const double ex = exp_nonpositive(-pend_a * pend_dz);
             I = fma(T * pend_aux, 1.0 - ex, I);
             T *= ex;
         }
