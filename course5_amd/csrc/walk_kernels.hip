@@ -724,7 +724,7 @@ using V2 = double __attribute__((ext_vector_type(2)));  // 16 bytes as one SSA v
 __device__ __forceinline__ D2 as_d2(V2 v) { return D2{v.x, v.y}; }
 
 template <int TILE, int ORDER>
-__global__ __launch_bounds__(256) void walk_composite_lds(WalkParams P) {
+__global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
     using TS = TileShape<TILE>;
     constexpr int TW = TS::WW * TS::GX, TH = TS::WH * TS::GY;
     constexpr bool kUp = (ORDER == 0);
@@ -789,7 +789,7 @@ __global__ __launch_bounds__(256) void walk_composite_lds(WalkParams P) {
 
     // contribution of the step whose record is being replaced (integrated while the next loads fly)
     bool pend = false;
-    double pend_dz = 0.0, pend_a_raw = 0.0, pend_a = 0.0, pend_aux = 0.0, pend_q = 0.0;
+    double pend_dz = 0.0, pend_a = 0.0, pend_aux = 0.0, pend_q = 0.0;
 
     while (true) {  // wave-uniform: every lane helps with the staging until all rays are done
         const bool need = nb >= 0;
@@ -826,8 +826,6 @@ __global__ __launch_bounds__(256) void walk_composite_lds(WalkParams P) {
 
         // ... while they are in flight: emission/absorption of the step just taken
         if (pend) {
-            ++n_seg;
-            tau = fma(pend_dz, pend_a_raw, tau);  // line.cpp:189
             if (ORDER == 0) {
                 if (pend_a != 0.0) I = reference_emission_step(I, pend_a, pend_q, pend_aux, pend_dz);  // line.cpp:220-224
             } else if (T >= P.t_cutoff) {
@@ -868,9 +866,10 @@ __global__ __launch_bounds__(256) void walk_composite_lds(WalkParams P) {
             const StepGeometry sg = step_geometry<kUp>(cur, x, y);
             ++n_step;
             if (sg.contributes) {
+                ++n_seg;
+                tau = fma(sg.dz, cur.o0.a, tau);  // line.cpp:189 (unclamped alpha); order-independent, done now
                 pend = true;
                 pend_dz = sg.dz;
-                pend_a_raw = cur.o0.a;
                 pend_a = cur.o0.b;
                 pend_aux = cur.o1.a;  // 1/alpha for the reference recurrence, Q/alpha otherwise
                 pend_q = cur.o1.b;
@@ -891,8 +890,6 @@ __global__ __launch_bounds__(256) void walk_composite_lds(WalkParams P) {
         }
     }
     if (pend) {  // the last step's contribution
-        ++n_seg;
-        tau = fma(pend_dz, pend_a_raw, tau);
         if (ORDER == 0) {
             if (pend_a != 0.0) I = reference_emission_step(I, pend_a, pend_q, pend_aux, pend_dz);
         } else if (T >= P.t_cutoff) {
