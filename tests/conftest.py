@@ -16,6 +16,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no binaries (they are git-ignored): build them once (hipcc cross-compiles
+    gfx950 without a GPU).  On the GPU box the prebuilt files travel with the snapshot."""
+    import shutil
+    from course5_amd import build as c5build
+    if not (os.path.exists(c5build.LIB) and os.path.exists(c5build.CLI)) and shutil.which("hipcc"):
+        c5build.build_all()
+
+
 @pytest.fixture(scope="session")
 def oracle_port():
     """CPU restatement of the reference algorithm (oracle/oracle.cpp) — the checker."""
