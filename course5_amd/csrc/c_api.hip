@@ -411,7 +411,8 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     wp.max_steps = static_cast<uint32_t>(ctx->n_cells + 64);
     wp.xcd_mode = ctx->xcd_mode;
     wp.order = ctx->order;
-    wp.lds_stage = ctx->lds_stage;
+    // walk_composite_lds addresses the records by 32-bit byte offsets: n_cells * 128 must fit
+    wp.lds_stage = (ctx->lds_stage && ctx->n_cells < (int64_t{1} << 25)) ? 1 : 0;
     wp.counters = fs.counters.as<c5::FrameCounters>();
     wp.row_cost = nullptr;
     wp.sticky = ctx->sticky.as<unsigned>();

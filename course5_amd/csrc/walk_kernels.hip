@@ -107,7 +107,9 @@ __global__ __launch_bounds__(256) void build_records(GridView g, double alpha_li
         const int pos = up ? up_pos : lo_pos;
         up_pos += up ? 1 : 0;
         lo_pos += up ? 0 : 1;
-        const uint32_t w = (nb[f] < 0) ? kNoCell : (static_cast<uint32_t>(nb[f]) & kIdMask);
+        // an edge-on face is crossed by no ray: its slot forwards nothing (the LDS walk relies on this
+        // to tell "left the grid" from the neighbour word alone)
+        const uint32_t w = (nb[f] < 0 || fp[f].kind == 0) ? kNoCell : (static_cast<uint32_t>(nb[f]) & kIdMask);
         const double c = (fp[f].kind == 0) ? INFINITY : fp[f].c;
         const double gx = (fp[f].kind == 0) ? 0.0 : fp[f].gx;
         const double gy = (fp[f].kind == 0) ? 0.0 : fp[f].gy;
@@ -133,6 +135,7 @@ __global__ __launch_bounds__(256) void build_records(GridView g, double alpha_li
         pl[2][0] = -INFINITY;
         pl[2][1] = pl[2][2] = 0.0;
         stored_up = 2;
+        words[0] = words[1] = words[2] = words[3] = kNoCell;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -423,6 +426,7 @@ struct alignas(16) D2 {
 // within ~1 ulp.  Underflows to 0 below -745 like exp().
 __device__ __forceinline__ double exp_nonpositive(double x) {
 #pragma clang fp contract(fast)
+    x = fmax(x, -746.0);  // k >= -1076: p * 2^k rounds to 0 there, as exp() does below -745.13
     const double k = rint(x * 1.4426950408889634074);  // log2(e)
     double r = fma(k, -6.93147180369123816490e-01, x);  // ln2 high part (exact product for |k| < 2^10)
     r = fma(k, -1.90821492927058770002e-10, r);         // ln2 low part
@@ -446,8 +450,7 @@ __device__ __forceinline__ double exp_nonpositive(double x) {
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    const double y = ldexp(p, static_cast<int>(k));
-    return (x < -745.2) ? 0.0 : y;
+    return ldexp(p, static_cast<int>(k));
 }
 
 // One emission/absorption step in the reference's own arithmetic (line.cpp:220-224):
@@ -719,17 +722,76 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
 // flight during step k's exp/divide work, as in the direct kernel.
 // ------------------------------------------------------------------------------------------
 constexpr int kStageSlots = 32;   // runs of equal cell ids staged per wavefront and step (more: direct loads)
-constexpr int kRecStride = 9;     // CellRecord stride in LDS, 16-byte units (128 B + 16 B pad)
+// One staged cell in LDS, 16-byte units: 8 of CellRecord, 2 of CellOptics, 1 pad.  176 bytes = 44 banks:
+// sixteen consecutive slots start on sixteen different 16-byte bank columns, so a ds_read_b128 whose
+// 16-lane groups span up to 16 different slots is conflict-free (MI355X_MICROARCH.md, LDS table).
+constexpr int kSlotStride = 11;
 using V2 = double __attribute__((ext_vector_type(2)));  // 16 bytes as one SSA value (never an alloca)
 __device__ __forceinline__ D2 as_d2(V2 v) { return D2{v.x, v.y}; }
+
+// min / max as ONE instruction.  fmin()/fmax() on a value the compiler cannot prove canonical (one
+// that went through integer selects) is preceded by a canonicalising v_max_f64 x, x; the operands
+// here are never signalling NaNs, and a quiet NaN operand is ignored (IEEE minNum / maxNum), which
+// step_geometry_fast uses on purpose.
+__device__ __forceinline__ double min_f64(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double max_f64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// step_geometry with the slot classification done on the HIGH WORD only: a slot that is not an upper
+// face takes part in the min as a quiet NaN (high word 0x7FF80000, low word left as it is), which
+// v_min_f64 ignores and no comparison ever equals — one v_cndmask per candidate instead of a 64-bit
+// select against +-inf.  Slots 0 (always upper) and 3 (always lower) are real numbers or +-inf, so
+// z_top and z_bot are never NaN.  Same results as step_geometry, bit for bit.
+template <bool kUp>
+__device__ __forceinline__ StepGeometry step_geometry_fast(const CellRegs& cur, double x, double y) {
+    const double dx = x - cur.r0.a, dy = y - cur.r0.b;
+    const double z0 = fma(cur.r1.b, dx, fma(cur.r2.a, dy, cur.r1.a));
+    const double z1 = fma(cur.r3.a, dx, fma(cur.r3.b, dy, cur.r2.b));
+    const double z2 = fma(cur.r4.b, dx, fma(cur.r5.a, dy, cur.r4.a));
+    const double z3 = fma(cur.r6.a, dx, fma(cur.r6.b, dy, cur.r5.b));
+    const unsigned long long w01 = __double_as_longlong(cur.r7.a);
+    const unsigned long long w23 = __double_as_longlong(cur.r7.b);
+    const uint32_t w0 = static_cast<uint32_t>(w01), w1 = static_cast<uint32_t>(w01 >> 32);
+    const uint32_t w2 = static_cast<uint32_t>(w23), w3 = static_cast<uint32_t>(w23 >> 32);
+    const uint32_t n_up = w0 >> kUpperCountShift;  // 1..3
+    const bool up1 = n_up > 1u, up2 = n_up > 2u;
+    constexpr int kQuietNan = 0x7FF80000;
+    const int z1h = __double2hiint(z1), z1l = __double2loint(z1);
+    const int z2h = __double2hiint(z2), z2l = __double2loint(z2);
+    const double u1 = __hiloint2double(up1 ? z1h : kQuietNan, z1l);
+    const double l1 = __hiloint2double(up1 ? kQuietNan : z1h, z1l);
+    const double u2 = __hiloint2double(up2 ? z2h : kQuietNan, z2l);
+    const double l2 = __hiloint2double(up2 ? kQuietNan : z2h, z2l);
+    const double z_top = min_f64(z0, min_f64(u1, u2));
+    const double z_bot = max_f64(z3, max_f64(l1, l2));
+    StepGeometry g;
+    g.dz = z_top - z_bot;
+    g.contributes = g.dz > 0.0 && g.dz < INFINITY;
+    if (kUp) {
+        g.w_out = (z0 == z_top) ? w0 : (u1 == z_top) ? w1 : w2;
+        g.has_exit = z_top < INFINITY;
+        g.s_exit = -z_top;
+    } else {
+        g.w_out = (z3 == z_bot) ? w3 : (l2 == z_bot) ? w2 : w1;
+        g.has_exit = z_bot > -INFINITY;
+        g.s_exit = z_bot;
+    }
+    return g;
+}
 
 template <int TILE, int ORDER>
 __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
     using TS = TileShape<TILE>;
     constexpr int TW = TS::WW * TS::GX, TH = TS::WH * TS::GY;
     constexpr bool kUp = (ORDER == 0);
-    __shared__ V2 s_rec[4][kStageSlots * kRecStride];
-    __shared__ V2 s_opt[4][kStageSlots * 2];
+    __shared__ V2 s_stage[4][kStageSlots * kSlotStride];
 
     const ImageParams& im = P.im;
     const int tiles_x = (im.res_x + TW - 1) / TW;
@@ -756,11 +818,15 @@ __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
     const int col = tx * TW + (wave % TS::GX) * TS::WW + (lane % TS::WW);
     const int lrow = ty * TH + (wave / TS::GX) * TS::WH + (lane / TS::WW);
     const bool in_image = (col < im.res_x) && (lrow < im.n_local_rows);
-    V2* const my_rec = s_rec[wave];
-    V2* const my_opt = s_opt[wave];
-    const unsigned long long lanes_le = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+    V2* const my_stage = s_stage[wave];
+    // records and optics are addressed as a uniform base + a 32-bit byte offset per lane (the host
+    // only picks this kernel while n_cells * 128 fits 32 bits): one shift-or per load instead of a
+    // 64-bit shift and a 64-bit add
+    const char* const rec_bytes = reinterpret_cast<const char*>(P.rec);
+    const char* const opt_bytes = reinterpret_cast<const char*>(P.opt);
 
-    unsigned n_seg = 0, n_step = 0, is_solid = 0, overflow = 0;
+    unsigned n_seg = 0, is_solid = 0, overflow = 0;
+    unsigned n_step_wave = 0;  // wave-uniform: lane-steps taken by the whole wavefront
     double tau = 0.0, I = 0.0, T = 1.0;
     double x = 0.0, y = 0.0, s_cur = DBL_MAX;
     int e0 = 0, e1 = 0, nb = -1;
@@ -788,49 +854,70 @@ __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
     }
 
     // contribution of the step whose record is being replaced (integrated while the next loads fly)
+    // (optics kept as the two 16-byte halves they are read in: {alpha_raw, alpha_c}, {aux, q})
     bool pend = false;
-    double pend_dz = 0.0, pend_a = 0.0, pend_aux = 0.0, pend_q = 0.0;
+    double pend_dz = 0.0;
+    V2 pend_o0 = {0.0, 0.0}, pend_o1 = {0.0, 0.0};
 
-    while (true) {  // wave-uniform: every lane helps with the staging until all rays are done
+    // lane-constant pieces of the staging addresses
+    static_assert(kStageSlots % 8 == 0 && kStageSlots <= 32, "whole passes of 8 slots, one optics pass");
+    constexpr int kPasses = kStageSlots / 8;
+    const int piece = lane & 7, sub = lane >> 3, so = lane >> 1;
+    const uint32_t rec_piece_off = static_cast<uint32_t>(piece) * 16u;
+    const uint32_t opt_piece_off = static_cast<uint32_t>(lane & 1) * 16u;
+    const int sub4 = sub << 2, so4 = so << 2;  // ds_bpermute byte addresses of slot `sub` / `so`
+    V2* const put_rec = my_stage + sub * kSlotStride + piece;         // + 8 * pass * kSlotStride
+    V2* const put_opt = my_stage + so * kSlotStride + 8 + (lane & 1);
+
+    // A lane steps in every iteration from its start to its end (re-entry takes no extra iteration), so
+    // the wave-uniform iteration count IS the step count of every lane still walking: the guard
+    // against malformed grids (never spin) is one scalar compare per iteration.
+    for (unsigned iter = 0;; ++iter) {
         const bool need = nb >= 0;
-        if (__ballot(need) == 0ull) break;
+        const unsigned long long needs = __builtin_amdgcn_ballot_w64(need);
+        if (needs == 0ull) break;
+        if (iter >= P.max_steps) {
+            if (need) overflow = 1;
+            break;
+        }
+        n_step_wave += static_cast<unsigned>(__popcll(needs));
 
-        // 1. runs of equal cell ids -> slots
-        const int left = __shfl_up(nb, 1);
-        const bool head = need && (lane == 0 || left != nb);
-        const unsigned long long heads = __ballot(head);
+        // 1. runs of equal cell ids -> slots.  `left` = nb of the lane to the left (DPP wave shift, one
+        //    VALU instruction, no LDS round trip); lane 0 reads 0 and is a head by decree.
+        const int left = __builtin_amdgcn_mov_dpp(nb, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+        const unsigned long long heads = (__builtin_amdgcn_ballot_w64(left != nb) | 1ull) & needs;
         const int n_runs = __popcll(heads);
-        const int slot = __popcll(heads & lanes_le) - 1;  // valid where need
+        // slot = (heads at or below this lane) - 1, as mbcnt over heads >> 1 seeded with (bit 0) - 1
+        const unsigned long long hs = heads >> 1;
+        const int slot = static_cast<int>(__builtin_amdgcn_mbcnt_hi(
+            static_cast<uint32_t>(hs >> 32),
+            __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hs), static_cast<uint32_t>(static_cast<int>(heads & 1ull) - 1))));
         const int n_staged = n_runs < kStageSlots ? n_runs : kStageSlots;
-        // lane s learns the cell id of slot s (forward permute from the run heads)
-        const int id_of_lane = __builtin_amdgcn_ds_permute((head ? slot : 63) << 2, head ? nb : -1);
-        // 2. cooperative loads into registers: record pieces (8 lanes per slot, 8 slots per pass)
-        // kPasses passes of 8 slots (8 lanes x 16 B per record) + one pass for the optics (2 lanes per
-        // slot).  Lanes beyond the staged slots re-load slot 0's piece (same cache line, free) so that
-        // the loads are unconditional and the values stay in registers.  Measured on the C3 frame
-        // (same GPU): 24 slots 1.31 ms, 32 slots 1.24 ms, 40 slots 1.38 ms and 48 slots 1.31 ms
-        // (registers: occupancy drops to 3 wavefronts per SIMD); a second staging round instead of the
-        // direct-load fallback 1.41 ms.
-        static_assert(kStageSlots % 8 == 0 && kStageSlots <= 32, "whole passes of 8 slots, one optics pass");
-        constexpr int kPasses = kStageSlots / 8;
-        const int piece = lane & 7, sub = lane >> 3, so = lane >> 1;
+        // lane s learns the cell id of slot s: every lane of a run pushes the same id to lane `slot`
+        // (finished rays push to lane 63, which is a slot only when all 64 lanes are heads).  Lanes
+        // nobody pushes to read 0 (ds_permute_b32 clears its buffer first; probed on gfx950,
+        // scripts/probes/lane_ops_probe.hip): cell 0's record, loaded and never used.
+        const int id_of_lane = __builtin_amdgcn_ds_permute(need ? (slot << 2) : 252, nb);
+        // 2. cooperative loads into registers: kPasses passes of 8 slots (8 lanes x 16 B per record)
+        //    + one pass for the optics (2 lanes per slot).  Measured on the C3 frame (same GPU): 24
+        //    slots 1.31 ms, 32 slots 1.24 ms, 40 slots 1.38 ms and 48 slots 1.31 ms (registers); a
+        //    second staging round instead of the direct-load fallback 1.41 ms.
         V2 stage_r[kPasses];
 #pragma unroll
         for (int pass = 0; pass < kPasses; ++pass) {  // fully unrolled: stage_r[] stays in registers
-            const int s_ = 8 * pass + sub;
-            const int id_ = __builtin_amdgcn_ds_bpermute((s_ < n_staged ? s_ : 0) << 2, id_of_lane);
-            stage_r[pass] = reinterpret_cast<const V2*>(P.rec + id_)[piece];
+            const uint32_t id_ = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(sub4 + 32 * pass, id_of_lane));
+            stage_r[pass] = *reinterpret_cast<const V2*>(rec_bytes + ((id_ << 7) | rec_piece_off));
         }
-        const int ido = __builtin_amdgcn_ds_bpermute((so < n_staged ? so : 0) << 2, id_of_lane);
-        const V2 stage_o0 = reinterpret_cast<const V2*>(P.opt + ido)[lane & 1];
+        const uint32_t ido = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(so4, id_of_lane));
+        const V2 stage_o0 = *reinterpret_cast<const V2*>(opt_bytes + ((ido << 5) | opt_piece_off));
 
         // ... while they are in flight: emission/absorption of the step just taken
         if (pend) {
             if (ORDER == 0) {
-                if (pend_a != 0.0) I = reference_emission_step(I, pend_a, pend_q, pend_aux, pend_dz);  // line.cpp:220-224
+                if (pend_o0.y != 0.0) I = reference_emission_step(I, pend_o0.y, pend_o1.y, pend_o1.x, pend_dz);  // line.cpp:220-224
             } else if (T >= P.t_cutoff) {
-                const double ex = exp_nonpositive(-pend_a * pend_dz);
-                I = fma(T * pend_aux, 1.0 - ex, I);
+                const double ex = exp_nonpositive(-pend_o0.y * pend_dz);
+                I = fma(T * pend_o1.x, 1.0 - ex, I);
                 T *= ex;
             }
             pend = false;
@@ -840,15 +927,17 @@ __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int pass = 0; pass < kPasses; ++pass)
-            if (8 * pass + sub < n_staged) my_rec[(8 * pass + sub) * kRecStride + piece] = stage_r[pass];
-        if (so < n_staged) my_opt[lane] = stage_o0;
+            if (sub < n_staged - 8 * pass) put_rec[8 * pass * kSlotStride] = stage_r[pass];
+        if (so < n_staged) *put_opt = stage_o0;
         __builtin_amdgcn_wave_barrier();
 
         // 4. every ray fetches its cell
-        CellRegs cur;
         if (need) {
-            if (slot < kStageSlots) {
-                const V2* r = my_rec + slot * kRecStride;
+            CellRegs cur;
+            const V2* r = reinterpret_cast<const V2*>(reinterpret_cast<const char*>(my_stage) +
+                                                      __umul24(static_cast<unsigned>(slot), kSlotStride * 16u));
+            const bool staged = slot < kStageSlots;
+            if (staged) {
                 cur.r0 = as_d2(r[0]);
                 cur.r1 = as_d2(r[1]);
                 cur.r2 = as_d2(r[2]);
@@ -857,33 +946,26 @@ __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
                 cur.r5 = as_d2(r[5]);
                 cur.r6 = as_d2(r[6]);
                 cur.r7 = as_d2(r[7]);
-                cur.o0 = as_d2(my_opt[slot * 2]);
-                cur.o1 = as_d2(my_opt[slot * 2 + 1]);
             } else {
                 load_cell(cur, P.rec, P.opt, nb);  // more distinct cells than slots: rare
             }
 
-            const StepGeometry sg = step_geometry<kUp>(cur, x, y);
-            ++n_step;
+            const StepGeometry sg = step_geometry_fast<kUp>(cur, x, y);
             if (sg.contributes) {
+                // the optics are only needed now: straight into the pending registers
+                pend_o0 = staged ? r[8] : V2{cur.o0.a, cur.o0.b};
+                pend_o1 = staged ? r[9] : V2{cur.o1.a, cur.o1.b};
                 ++n_seg;
-                tau = fma(sg.dz, cur.o0.a, tau);  // line.cpp:189 (unclamped alpha); order-independent, done now
+                tau = fma(sg.dz, pend_o0.x, tau);  // line.cpp:189 (unclamped alpha); order-independent, done now
                 pend = true;
                 pend_dz = sg.dz;
-                pend_a = cur.o0.b;
-                pend_aux = cur.o1.a;  // 1/alpha for the reference recurrence, Q/alpha otherwise
-                pend_q = cur.o1.b;
             }
-            int nxt = -1;
-            if (sg.has_exit) {
-                s_cur = fmin(s_cur, sg.s_exit);
-                const uint32_t id = sg.w_out & kIdMask;
-                if (id != kNoCell) nxt = static_cast<int>(id);
-            }
-            if (nxt >= 0 && n_step >= P.max_steps) {
-                overflow = 1;
-                nxt = -1;
-            } else if (nxt < 0 && !overflow) {
+            // an edge-on or flat slot forwards nothing (build_records), so the neighbour word alone
+            // says whether the ray goes on inside the grid
+            const uint32_t id = sg.w_out & kIdMask;
+            int nxt = static_cast<int>(id);
+            if (id == kNoCell) {  // left the grid: re-entry of a non-convex grid?
+                if (sg.has_exit) s_cur = fmin(s_cur, sg.s_exit);
                 nxt = next_entry<kUp>(P.entries, e0, e1, s_cur);
             }
             nb = nxt;
@@ -891,10 +973,10 @@ __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
     }
     if (pend) {  // the last step's contribution
         if (ORDER == 0) {
-            if (pend_a != 0.0) I = reference_emission_step(I, pend_a, pend_q, pend_aux, pend_dz);
+            if (pend_o0.y != 0.0) I = reference_emission_step(I, pend_o0.y, pend_o1.y, pend_o1.x, pend_dz);
         } else if (T >= P.t_cutoff) {
-            const double ex = exp_nonpositive(-pend_a * pend_dz);
-            I = fma(T * pend_aux, 1.0 - ex, I);
+            const double ex = exp_nonpositive(-pend_o0.y * pend_dz);
+            I = fma(T * pend_o1.x, 1.0 - ex, I);
             T *= ex;
         }
     }
@@ -915,13 +997,12 @@ __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
         if ((lane % TS::WW) == 0 && rs && lrow < im.n_local_rows) atomicAdd(P.row_cost + lrow, rs);
     }
     const unsigned s_seg = wave_sum_u32(n_seg);
-    const unsigned s_step = wave_sum_u32(n_step);
     const unsigned s_cov = wave_sum_u32(n_seg > 0 ? 1u : 0u);
     const unsigned s_sol = wave_sum_u32(is_solid);
     const unsigned s_ovf = wave_sum_u32(overflow);
     if (lane == 0) {
         if (s_seg) atomicAdd(&P.counters->segments, static_cast<unsigned long long>(s_seg));
-        if (s_step) atomicAdd(&P.counters->steps, static_cast<unsigned long long>(s_step));
+        if (n_step_wave) atomicAdd(&P.counters->steps, static_cast<unsigned long long>(n_step_wave));
         if (s_cov) atomicAdd(&P.counters->covered, static_cast<unsigned long long>(s_cov));
         if (s_sol) atomicAdd(&P.counters->solid_pixels, static_cast<unsigned long long>(s_sol));
         if (s_ovf) {
