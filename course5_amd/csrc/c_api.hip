@@ -114,6 +114,7 @@ struct c5_context {
     double t_cutoff = 1e-12;
     int tile_shape = 0;
     int xcd_mode = 1;
+    int lds_pad = 0;
     int order = 0;
     int lds_stage = 1;
     int stage_timing = 1;
@@ -410,6 +411,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     wp.t_cutoff = ctx->t_cutoff;
     wp.max_steps = static_cast<uint32_t>(ctx->n_cells + 64);
     wp.xcd_mode = ctx->xcd_mode;
+    wp.lds_pad = ctx->lds_pad;
     wp.order = ctx->order;
     // walk_composite_lds addresses the records by 32-bit byte offsets: n_cells * 128 must fit
     wp.lds_stage = (ctx->lds_stage && ctx->n_cells < (int64_t{1} << 25)) ? 1 : 0;
@@ -897,6 +899,9 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
         ctx->lds_stage = static_cast<int>(value) != 0;
     } else if (n == "integration") {
         ctx->order = static_cast<int>(value) != 0;
+    } else if (n == "lds_pad") {  // tuning: occupancy experiments (scripts/occupancy_sweep.py)
+        if (value < 0 || value > 96 * 1024) return fail(ctx, C5_ERR_INVALID, "lds_pad out of range");
+        ctx->lds_pad = static_cast<int>(value);
     } else if (n == "xcd_mode") {
         ctx->xcd_mode = static_cast<int>(value) != 0;
     } else if (n == "row_costs") {

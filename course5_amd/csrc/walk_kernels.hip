@@ -786,6 +786,25 @@ __device__ __forceinline__ StepGeometry step_geometry_fast(const CellRegs& cur, 
     return g;
 }
 
+// Optional in-kernel phase clock (build with -DC5_WALK_STAMPS=1; scripts/stamp_walk.py): every wavefront
+// sums, per phase of a step, the shader cycles between stamps; lane 0 adds them to g_walk_stamps.
+#ifndef C5_WALK_STAMPS
+#define C5_WALK_STAMPS 0
+#endif
+#if C5_WALK_STAMPS
+__device__ unsigned long long g_walk_stamps[16];
+#define C5_STAMP(k)                                              \
+    do {                                                         \
+        const unsigned long long t_now_ = __builtin_amdgcn_s_memtime(); \
+        stamp_acc[k] += t_now_ - t_prev_;                        \
+        t_prev_ = t_now_;                                        \
+    } while (0)
+#else
+#define C5_STAMP(k) \
+    do {            \
+    } while (0)
+#endif
+
 template <int TILE, int ORDER>
 __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
     using TS = TileShape<TILE>;
@@ -872,6 +891,11 @@ __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
     // A lane steps in every iteration from its start to its end (re-entry takes no extra iteration), so
     // the wave-uniform iteration count IS the step count of every lane still walking: the guard
     // against malformed grids (never spin) is one scalar compare per iteration.
+#if C5_WALK_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_begin_ = t_prev_;
+#endif
     for (unsigned iter = 0;; ++iter) {
         const bool need = nb >= 0;
         const unsigned long long needs = __builtin_amdgcn_ballot_w64(need);
@@ -898,6 +922,10 @@ __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
         // nobody pushes to read 0 (ds_permute_b32 clears its buffer first; probed on gfx950,
         // scripts/probes/lane_ops_probe.hip): cell 0's record, loaded and never used.
         const int id_of_lane = __builtin_amdgcn_ds_permute(need ? (slot << 2) : 252, nb);
+#if C5_WALK_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(id_of_lane));
+        C5_STAMP(0);  // runs -> slots, ds_permute landed
+#endif
         // 2. cooperative loads into registers: kPasses passes of 8 slots (8 lanes x 16 B per record)
         //    + one pass for the optics (2 lanes per slot).  Measured on the C3 frame (same GPU): 24
         //    slots 1.31 ms, 32 slots 1.24 ms, 40 slots 1.38 ms and 48 slots 1.31 ms (registers); a
@@ -910,6 +938,7 @@ __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
         }
         const uint32_t ido = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(so4, id_of_lane));
         const V2 stage_o0 = *reinterpret_cast<const V2*>(opt_bytes + ((ido << 5) | opt_piece_off));
+        C5_STAMP(1);  // bpermutes landed, five loads issued
 
         // ... while they are in flight: emission/absorption of the step just taken
         if (pend) {
@@ -922,6 +951,7 @@ __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
             }
             pend = false;
         }
+        C5_STAMP(2);  // emission/absorption of the previous step
 
         // 3. park the pieces in LDS (the previous step's reads are long done: same wavefront, in order)
         __builtin_amdgcn_wave_barrier();
@@ -930,6 +960,10 @@ __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
             if (sub < n_staged - 8 * pass) put_rec[8 * pass * kSlotStride] = stage_r[pass];
         if (so < n_staged) *put_opt = stage_o0;
         __builtin_amdgcn_wave_barrier();
+#if C5_WALK_STAMPS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        C5_STAMP(3);  // loads landed, pieces parked in LDS
+#endif
 
         // 4. every ray fetches its cell
         if (need) {
@@ -970,7 +1004,18 @@ __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
             }
             nb = nxt;
         }
+#if C5_WALK_STAMPS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        C5_STAMP(4);  // record read back, geometry, exit face, (re-entry)
+#endif
     }
+#if C5_WALK_STAMPS
+    if (lane == 0) {
+        for (int k = 0; k < 5; ++k) atomicAdd(&g_walk_stamps[k], stamp_acc[k]);
+        atomicAdd(&g_walk_stamps[8], __builtin_amdgcn_s_memtime() - t_begin_);  // whole loop
+        atomicAdd(&g_walk_stamps[9], 1ull);                                      // wavefronts
+    }
+#endif
     if (pend) {  // the last step's contribution
         if (ORDER == 0) {
             if (pend_o0.y != 0.0) I = reference_emission_step(I, pend_o0.y, pend_o1.y, pend_o1.x, pend_dz);
@@ -1012,6 +1057,17 @@ __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
     }
 }
 
+#if C5_WALK_STAMPS
+extern "C" int c5_debug_walk_stamps(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_walk_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_walk_stamps), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
+
 template <int TILE, int ORDER>
 static void launch_walk_t(hipStream_t s, const WalkParams& p) {
     using TS = TileShape<TILE>;
@@ -1032,13 +1088,13 @@ static void launch_walk_t(hipStream_t s, const WalkParams& p) {
         WalkParams q = p;
         q.band_tiles = band;
         if (p.lds_stage)
-            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, q);
+            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, q);
         else
             hipLaunchKernelGGL((walk_composite<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, q);
         return;
     }
     if (p.lds_stage)
-        hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, p);
     else
         hipLaunchKernelGGL((walk_composite<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
 }

@@ -1,0 +1,27 @@
+"""Scratch: phase clock of walk_composite_lds (library built with -DC5_WALK_STAMPS=1, see walk_kernels.hip).
+
+    C5_LIB=course5_amd/libcourse5_hip_stamps.so python scripts/stamp_walk.py
+"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from course5_amd import capi, meshgen as mg
+ctx = capi.Context(0)
+xyz, c, a, q = mg.workload("c3")
+ctx.upload_grid(xyz, c, a, q)
+ctx.set_image(2400, 1800, mg.REFERENCE_BOUNDS)
+ctx.set_view(mg.view_rotations(0.1, 0.07))
+lib = capi.load_library()
+buf = (C.c_ulonglong * 16)()
+for i in range(3):
+    ctx.render()
+lib.c5_debug_walk_stamps(buf, 1)
+ctx.render()
+st = ctx.stats()
+lib.c5_debug_walk_stamps(buf, 1)
+v = list(buf)
+names = ["runs->slots + ds_permute", "bpermutes + load issue", "emission step (exp)", "loads land + ds_write", "ds_read + geometry + exit"]
+tot = sum(v[:5])
+steps_wave = st["steps"] / 64.0
+print("walk ms", st["ms_walk"], "lane-steps", st["steps"], "wavefronts", v[9], "loop cycles/wave", v[8] / max(v[9], 1))
+for n, x in zip(names, v[:5]):
+    print(f"{n:32s} {x:14d} cycles  {100.0 * x / tot:5.1f} %")
