@@ -60,12 +60,13 @@ struct Solid {
 
 constexpr int kWalkEventPool = 512;
 constexpr int kFrameSlots = 2;
+constexpr size_t kCountersBytes = sizeof(c5::FrameCounters) * c5::kCounterShards;  // device_types.hpp
 
 // Everything one frame writes before its image: two slots, so that the per-view setup of frame
 // k + 1 (HBM-bound: transform, records, entry lists, solid mask) can run on the auxiliary stream
 // while walk_composite of frame k (VALU / address-path bound) runs on the main stream.
 struct FrameSlot {
-    DeviceBuffer vx, vy, vz, rec, opt, count, offs, scratch, entries, mask, counters, row_cost;
+    DeviceBuffer vx, vy, vz, rec, opt, count, head, first, pool, mask, counters, row_cost;
     int64_t entry_capacity = 0;
     c5::FrameCounters* host_counters = nullptr;  // pinned
     hipEvent_t setup_done = nullptr, walk_done = nullptr;
@@ -202,13 +203,13 @@ int ensure_image_buffers(c5_context* ctx) {
     for (int k = 0; k < (ctx->pipeline ? kFrameSlots : 1); ++k) {
         FrameSlot& fs = ctx->slots[k];
         C5_HIP(ctx, fs.count.ensure(static_cast<size_t>(padded + 1024) * sizeof(int32_t)));
-        C5_HIP(ctx, fs.offs.ensure(static_cast<size_t>(padded + 1024) * sizeof(int32_t)));
-        C5_HIP(ctx, fs.scratch.ensure(static_cast<size_t>(padded / 1024 + 1024) * sizeof(int32_t)));
+        C5_HIP(ctx, fs.head.ensure(static_cast<size_t>(padded) * sizeof(c5::EntryHead)));
+        C5_HIP(ctx, fs.first.ensure(static_cast<size_t>(padded) * sizeof(c5::Entry)));
         C5_HIP(ctx, fs.mask.ensure(static_cast<size_t>(padded) * sizeof(uint32_t)));
         C5_HIP(ctx, fs.row_cost.ensure(static_cast<size_t>(im.n_local_rows + 64) * sizeof(uint32_t)));
-        if (fs.entry_capacity < 2 * n_px + 1024) {
-            fs.entry_capacity = 2 * n_px + 1024;
-            C5_HIP(ctx, fs.entries.ensure(static_cast<size_t>(fs.entry_capacity) * sizeof(c5::Entry)));
+        if (fs.entry_capacity < n_px / 8 + 1024) {  // overflow pool: re-entries only; grows on demand (C5_RETRY)
+            fs.entry_capacity = n_px / 8 + 1024;
+            C5_HIP(ctx, fs.pool.ensure(static_cast<size_t>(fs.entry_capacity) * sizeof(c5::Entry)));
         }
     }
     return C5_OK;
@@ -278,7 +279,7 @@ int enqueue_bin_sort(c5_context* ctx, FrameSlot& fs, const c5::GridView& g, int 
                        table, ctx->alpha_limit, out_dev, fs.counters.as<c5::FrameCounters>());
     C5_HIP(ctx, mark(5, s));
     C5_HIP(ctx, hipGetLastError());
-    C5_HIP(ctx, hipMemcpyAsync(fs.host_counters, fs.counters.ptr, sizeof(c5::FrameCounters), hipMemcpyDeviceToHost, s));
+    C5_HIP(ctx, hipMemcpyAsync(fs.host_counters, fs.counters.ptr, kCountersBytes, hipMemcpyDeviceToHost, s));
     C5_HIP(ctx, hipMemcpyAsync(ctx->host_sticky, ctx->sticky.ptr, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     C5_HIP(ctx, hipStreamSynchronize(s));
     fs.host_counters->segments = static_cast<unsigned long long>(total);
@@ -323,7 +324,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     if (ctx->pipeline && fs.walk_recorded) C5_HIP(ctx, hipStreamWaitEvent(s, fs.walk_done, 0));
 
     C5_HIP(ctx, mark(0, s));
-    C5_HIP(ctx, hipMemsetAsync(fs.counters.ptr, 0, sizeof(c5::FrameCounters), s));
+    C5_HIP(ctx, hipMemsetAsync(fs.counters.ptr, 0, kCountersBytes, s));
 
     c5::GridView g;
     g.n_pts = ctx->n_pts;
@@ -371,18 +372,12 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     }
     c5::launch_build_records(s, g, ctx->alpha_limit, ctx->order);
     C5_HIP(ctx, mark(2, s));
-    // boundary entries: count -> scan -> fill
-    C5_HIP(ctx, hipMemsetAsync(fs.count.ptr, 0, static_cast<size_t>(padded + 1) * sizeof(int32_t), e));
+    // boundary entries: one raster pass (per-pixel count + first entry + overflow chain)
+    C5_HIP(ctx, hipMemsetAsync(fs.head.ptr, 0, static_cast<size_t>(padded) * sizeof(c5::EntryHead), e));
     if (g.n_cells > 0) {
-        c5::launch_entry_count(e, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im, fs.count.as<int32_t>(),
-                                ctx->order != 0);
-    }
-    c5::launch_exclusive_scan(e, fs.count.as<int32_t>(), fs.offs.as<int32_t>(), n_px, fs.scratch.as<int32_t>(),
-                              fs.counters.as<c5::FrameCounters>(), ctx->sticky.as<unsigned>());
-    if (g.n_cells > 0) {
-        c5::launch_entry_fill(e, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im, fs.count.as<int32_t>(),
-                              fs.offs.as<int32_t>(), fs.entries.as<c5::Entry>(), fs.entry_capacity,
-                              fs.counters.as<c5::FrameCounters>(), ctx->order != 0);
+        c5::launch_entry_lists(e, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im, fs.head.as<c5::EntryHead>(),
+                               fs.first.as<c5::Entry>(), fs.pool.as<c5::Entry>(), fs.entry_capacity,
+                               fs.counters.as<c5::FrameCounters>(), ctx->sticky.as<unsigned>(), ctx->order != 0);
     }
     C5_HIP(ctx, mark(3, e));
     // (a9) solids
@@ -400,8 +395,10 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     c5::WalkParams wp{};
     wp.rec = g.rec;
     wp.opt = g.opt;
-    wp.entry_offs = fs.offs.as<int32_t>();
-    wp.entries = fs.entries.as<c5::Entry>();
+    wp.entry_head = fs.head.as<c5::EntryHead>();
+    wp.entry_first = fs.first.as<c5::Entry>();
+    wp.entry_pool = fs.pool.as<c5::Entry>();
+    wp.pool_capacity = fs.entry_capacity;
     wp.mask = any_solid ? fs.mask.as<uint32_t>() : nullptr;
     wp.solids = table;
     wp.Xtab = ctx->xtab.as<double>();
@@ -446,7 +443,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     if (ev_slot >= 0) C5_HIP(ctx, hipEventRecord(ctx->walk_b[ev_slot], main_s));
     C5_HIP(ctx, mark(5, main_s));
     C5_HIP(ctx, hipGetLastError());
-    C5_HIP(ctx, hipMemcpyAsync(fs.host_counters, fs.counters.ptr, sizeof(c5::FrameCounters), hipMemcpyDeviceToHost, main_s));
+    C5_HIP(ctx, hipMemcpyAsync(fs.host_counters, fs.counters.ptr, kCountersBytes, hipMemcpyDeviceToHost, main_s));
     C5_HIP(ctx, hipMemcpyAsync(ctx->host_sticky, ctx->sticky.ptr, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, main_s));
     if (ctx->pipeline) {
         C5_HIP(ctx, hipEventRecord(fs.walk_done, main_s));
@@ -464,7 +461,19 @@ int finish_frame(c5_context* ctx) {
     if (!ctx->frame_pending) return C5_OK;
     ctx->frame_pending = false;
     FrameSlot& fs = ctx->slots[ctx->last_slot];
-    const c5::FrameCounters& hc = *fs.host_counters;
+    c5::FrameCounters hc{};  // sum of the shards
+    for (int k = 0; k < c5::kCounterShards; ++k) {
+        const c5::FrameCounters& p = fs.host_counters[k];
+        hc.segments += p.segments;
+        hc.steps += p.steps;
+        hc.covered += p.covered;
+        hc.solid_pixels += p.solid_pixels;
+        hc.entries += p.entries;
+        hc.walk_overflow += p.walk_overflow;
+        hc.entry_overflow += p.entry_overflow;
+        hc.odd_pixels += p.odd_pixels;
+        hc.pool_used += p.pool_used;
+    }
     c5_stats& st = ctx->last;
     st.segments = static_cast<int64_t>(hc.segments);
     st.covered_pixels = static_cast<int64_t>(hc.covered);
@@ -496,7 +505,7 @@ int finish_frame(c5_context* ctx) {
             FrameSlot& o = ctx->slots[k];
             if (o.entry_capacity >= want) continue;
             o.entry_capacity = want;
-            C5_HIP(ctx, o.entries.ensure(static_cast<size_t>(want) * sizeof(c5::Entry)));
+            C5_HIP(ctx, o.pool.ensure(static_cast<size_t>(want) * sizeof(c5::Entry)));
         }
         return fail(ctx, C5_RETRY, "entry buffer grown to %lld records; render the frame(s) again",
                     static_cast<long long>(want));
@@ -565,11 +574,11 @@ int c5_create(int device_ordinal, c5_context** out_ctx) {
             if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
         if ((e = hipEventCreateWithFlags(&fs.setup_done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
         if ((e = hipEventCreateWithFlags(&fs.walk_done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
-        if ((e = fs.counters.ensure(sizeof(c5::FrameCounters))) != hipSuccess) return bail(e, "hipMalloc");
-        if ((e = hipHostMalloc(reinterpret_cast<void**>(&fs.host_counters), sizeof(c5::FrameCounters),
-                               hipHostMallocDefault)) != hipSuccess)
+        if ((e = fs.counters.ensure(kCountersBytes)) != hipSuccess) return bail(e, "hipMalloc");
+        if ((e = hipHostMalloc(reinterpret_cast<void**>(&fs.host_counters), kCountersBytes, hipHostMallocDefault)) !=
+            hipSuccess)
             return bail(e, "hipHostMalloc");
-        std::memset(fs.host_counters, 0, sizeof(c5::FrameCounters));
+        std::memset(fs.host_counters, 0, kCountersBytes);
     }
     for (int k = 0; k < kWalkEventPool; ++k) {
         ctx->walk_a[k] = ctx->walk_b[k] = nullptr;
@@ -600,8 +609,8 @@ void c5_destroy(c5_context* ctx) {
     if (ctx->host_sticky) (void)hipHostFree(ctx->host_sticky);
     for (DeviceBuffer* b : bufs) b->release();
     for (FrameSlot& fs : ctx->slots) {
-        DeviceBuffer* sb[] = {&fs.vx, &fs.vy, &fs.vz, &fs.rec, &fs.opt, &fs.count, &fs.offs, &fs.scratch,
-                              &fs.entries, &fs.mask, &fs.counters, &fs.row_cost};
+        DeviceBuffer* sb[] = {&fs.vx, &fs.vy, &fs.vz, &fs.rec, &fs.opt, &fs.count, &fs.head, &fs.first, &fs.pool,
+                              &fs.mask, &fs.counters, &fs.row_cost};
         for (DeviceBuffer* b : sb) b->release();
         if (fs.host_counters) (void)hipHostFree(fs.host_counters);
         for (auto& ev : fs.ev)

@@ -53,11 +53,18 @@ struct alignas(16) CellOptics {
 };
 static_assert(sizeof(CellOptics) == 32, "CellOptics is 32 bytes");
 
-// A place where a ray enters the grid through a boundary face (walking from +z to -z).
+// A place where a ray enters the grid through a boundary face.  first[pixel] holds a pixel's first
+// entry; further ones live in the overflow pool, chained through `next` (pool slot + 1, 0 = end).
 struct alignas(16) Entry {
     double z;
     int32_t cell;
-    int32_t pad;
+    int32_t next;
+};
+// Per pixel and frame: number of entries and the head of the pixel's overflow chain (pool slot + 1).
+// Cleared to zero before every raster pass.
+struct alignas(8) EntryHead {
+    int32_t count;
+    int32_t chain;
 };
 
 constexpr int kMaxRotations = 8;
@@ -84,7 +91,13 @@ struct SolidTable {
     double colour[kMaxSolids];  // mask value v > 0 means "covered by solid slot v - 1"
 };
 
-struct FrameCounters {
+// Per-frame statistics.  The device holds kCounterShards copies, each on a 128-byte line of its own:
+// thousands of wavefronts adding to ONE address serialise at ~10 ns per atomic (three per covered
+// wavefront used to put a 0.7 ms floor under the C3 walk); spread over 64 lines they vanish.  The host
+// sums the shards (finish_frame).  Single-instance fields (pool_used, odd_pixels, the overflow flags)
+// live in shard 0.
+constexpr int kCounterShards = 64;
+struct alignas(128) FrameCounters {
     unsigned long long segments;
     unsigned long long steps;
     unsigned long long covered;
@@ -93,7 +106,7 @@ struct FrameCounters {
     unsigned int walk_overflow;
     unsigned int entry_overflow;
     unsigned int odd_pixels;  // bin_sort_resolve: (pixel, cell) pairs with an odd number of covering faces
-    unsigned int pad;
+    unsigned int pool_used;   // overflow entries handed out by entry_raster this frame
 };
 
 // global row -> local row of this rank, or -1

@@ -27,8 +27,10 @@ struct GridView {  // device pointers of the persistent grid + per-view buffers
 struct WalkParams {
     const CellRecord* rec;
     const CellOptics* opt;
-    const int32_t* entry_offs;  // [n_local_px + 1]
-    const Entry* entries;
+    const EntryHead* entry_head; // [n_local_px] entries of the pixel + overflow chain
+    const Entry* entry_first;   // [n_local_px] first entry (valid where entry_count > 0)
+    const Entry* entry_pool;    // overflow entries, chained from entry_first[].next
+    int64_t pool_capacity;
     const uint32_t* mask;       // [n_local_px] or nullptr
     SolidTable solids;
     const double* Xtab;
@@ -68,14 +70,9 @@ size_t segment_bytes();
 
 // walk_kernels.hip
 void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, int order);
-void launch_entry_count(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
-                        const ImageParams& im, int32_t* count, int want_upper);
-void launch_entry_fill(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
-                       const ImageParams& im, int32_t* count, const int32_t* offs, Entry* entries,
-                       int64_t capacity, FrameCounters* counters, int want_upper);
-// exclusive scan of count[n] into offs[n + 1]; scratch holds >= (n / 1024 + 2) int32
-void launch_exclusive_scan(hipStream_t s, const int32_t* count, int32_t* offs, int64_t n,
-                           int32_t* scratch, FrameCounters* counters, unsigned* sticky);
+void launch_entry_lists(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
+                        const ImageParams& im, EntryHead* head, Entry* first, Entry* pool, int64_t capacity,
+                        FrameCounters* counters, unsigned* sticky, int want_upper);
 void launch_walk(hipStream_t s, const WalkParams& p, int tile_shape);
 
 }  // namespace c5

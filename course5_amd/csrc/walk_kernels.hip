@@ -172,15 +172,21 @@ void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, 
 }
 
 // ------------------------------------------------------------------------------------------
-// entry_raster: one wavefront per boundary face
+// entry_raster: one wavefront per boundary face, ONE pass.
+//
+// Per covered pixel: old = atomicAdd(head[pixel].count, 1).  The first entry of a pixel (old == 0)
+// goes straight into the dense array first[pixel] as one full 16-byte store; every further one
+// (re-entry of a non-convex grid: rare) takes a slot of the overflow pool and hooks itself into the
+// pixel's chain with one atomicExch on head[pixel].chain (slot + 1; 0 ends a chain).  The walk reads
+// head[pixel], first[pixel] and the chain.  No scan over the pixels and no second raster pass
+// (count -> scan -> fill took 35 + 30 + 52 us on the C3 frame); first[] is never cleared, only the
+// 8-byte heads are.
 // ------------------------------------------------------------------------------------------
-template <int PASS>
 __global__ __launch_bounds__(256) void entry_raster(GridView g, const double* __restrict__ Xtab,
                                                     const double* __restrict__ Ytab, ImageParams im,
-                                                    int32_t* __restrict__ count,
-                                                    const int32_t* __restrict__ offs,
-                                                    Entry* __restrict__ entries, int64_t capacity,
-                                                    FrameCounters* counters, int want_upper) {
+                                                    EntryHead* __restrict__ head, Entry* __restrict__ first,
+                                                    Entry* __restrict__ pool, int64_t capacity,
+                                                    FrameCounters* counters, unsigned* sticky, int want_upper) {
     const int lane = threadIdx.x & 63;
     const int64_t face_idx = blockIdx.x * 4ll + (threadIdx.x >> 6);
     if (face_idx >= g.n_bfaces) return;
@@ -244,150 +250,68 @@ __global__ __launch_bounds__(256) void entry_raster(GridView g, const double* __
     const double x0 = p[0][0], y0 = p[0][1];
     const double pc = fp.c, pgx = fp.gx, pgy = fp.gy;
 
-    for (int64_t idx = lane; idx < n_box; idx += 64) {
-        const int row = r0 + static_cast<int>(idx / bw);
-        const int col = c0 + static_cast<int>(idx % bw);
-        const int lrow = local_row_of(im, row);
-        if (lrow < 0) continue;
-        const double x = Xtab[col], y = Ytab[row];
-        // closed point-in-triangle test, either winding
-        const double e0 = (bx - ax) * (y - ay) - (by - ay) * (x - ax);
-        const double e1 = (cx - bx) * (y - by) - (cy - by) * (x - bx);
-        const double e2 = (ax - cx) * (y - cy) - (ay - cy) * (x - cx);
-        const bool in = (e0 >= 0 && e1 >= 0 && e2 >= 0) || (e0 <= 0 && e1 <= 0 && e2 <= 0);
-        if (!in) continue;
-        const size_t lp = static_cast<size_t>(lrow) * im.res_x + col;
-        if (PASS == 0) {
-            atomicAdd(count + lp, 1);
-        } else {
-            const int k = atomicSub(count + lp, 1) - 1;
-            const int64_t slot = static_cast<int64_t>(offs[lp]) + k;
-            if (slot < capacity) {
+    for (int64_t base = 0; base < n_box; base += 64) {
+        const int64_t idx = base + lane;
+        bool in = false;
+        size_t lp = 0;
+        double x = 0.0, y = 0.0;
+        if (idx < n_box) {
+            const int row = r0 + static_cast<int>(idx / bw);
+            const int col = c0 + static_cast<int>(idx % bw);
+            const int lrow = local_row_of(im, row);
+            if (lrow >= 0) {
+                x = Xtab[col];
+                y = Ytab[row];
+                // closed point-in-triangle test, either winding
+                const double e0 = (bx - ax) * (y - ay) - (by - ay) * (x - ax);
+                const double e1 = (cx - bx) * (y - by) - (cy - by) * (x - bx);
+                const double e2 = (ax - cx) * (y - cy) - (ay - cy) * (x - cx);
+                in = (e0 >= 0 && e1 >= 0 && e2 >= 0) || (e0 <= 0 && e1 <= 0 && e2 <= 0);
+                lp = static_cast<size_t>(lrow) * im.res_x + col;
+            }
+        }
+        const double z = pc + pgx * (x - x0) + pgy * (y - y0);
+        const int old = in ? atomicAdd(&head[lp].count, 1) : 0;
+        if (in && old == 0) {
+            Entry e;
+            e.z = z;
+            e.cell = static_cast<int32_t>(cell);
+            e.next = 0;
+            first[lp] = e;
+        }
+        // further entries: one pool allocation per wavefront and iteration (same-address atomics serialise)
+        const bool more = in && old > 0;
+        const unsigned long long more_mask = __builtin_amdgcn_ballot_w64(more);
+        if (more_mask == 0ull) continue;
+        unsigned pool_base = 0;
+        if (lane == __builtin_ctzll(more_mask))
+            pool_base = atomicAdd(&counters->pool_used, static_cast<unsigned>(__popcll(more_mask)));
+        pool_base = __builtin_amdgcn_readlane(pool_base, __builtin_ctzll(more_mask));
+        if (more) {
+            const unsigned slot = pool_base + static_cast<unsigned>(__popcll(more_mask & ((1ull << lane) - 1ull)));
+            if (static_cast<int64_t>(slot) < capacity) {
                 Entry e;
-                e.z = pc + pgx * (x - x0) + pgy * (y - y0);
+                e.z = z;
                 e.cell = static_cast<int32_t>(cell);
-                e.pad = 0;
-                entries[slot] = e;
+                e.next = atomicExch(&head[lp].chain, static_cast<int32_t>(slot) + 1);
+                pool[slot] = e;
             } else {
+                // pool too small: the host sees the demand in sticky[0], grows the pool and renders again
+                // (the walk bounds-checks every hop, so this frame is merely wrong, never unsafe)
                 atomicOr(&counters->entry_overflow, 1u);
+                atomicMax(sticky, slot + 1u);
             }
         }
     }
 }
 
-void launch_entry_count(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
-                        const ImageParams& im, int32_t* count, int want_upper) {
+void launch_entry_lists(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
+                        const ImageParams& im, EntryHead* head, Entry* first, Entry* pool, int64_t capacity,
+                        FrameCounters* counters, unsigned* sticky, int want_upper) {
     if (g.n_bfaces <= 0) return;
     const unsigned blocks = static_cast<unsigned>((g.n_bfaces + 3) / 4);
-    hipLaunchKernelGGL(entry_raster<0>, dim3(blocks), dim3(256), 0, s, g, Xtab, Ytab, im, count,
-                       static_cast<const int32_t*>(nullptr), static_cast<Entry*>(nullptr),
-                       static_cast<int64_t>(0), static_cast<FrameCounters*>(nullptr), want_upper);
-}
-
-void launch_entry_fill(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
-                       const ImageParams& im, int32_t* count, const int32_t* offs, Entry* entries,
-                       int64_t capacity, FrameCounters* counters, int want_upper) {
-    if (g.n_bfaces <= 0) return;
-    const unsigned blocks = static_cast<unsigned>((g.n_bfaces + 3) / 4);
-    hipLaunchKernelGGL(entry_raster<1>, dim3(blocks), dim3(256), 0, s, g, Xtab, Ytab, im, count, offs,
-                       entries, capacity, counters, want_upper);
-}
-
-// ------------------------------------------------------------------------------------------
-// exclusive scan (int32), 1024 items per block
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(v, d);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
-
-// returns the exclusive prefix of `v` over the 256 threads of the block, total in *block_total
-__device__ __forceinline__ int block_exclusive_scan(int v, int* block_total) {
-    __shared__ int wave_sums[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int inc = wave_inclusive_scan(v, lane);
-    if (lane == 63) wave_sums[wave] = inc;
-    __syncthreads();
-    int base = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (k < wave) base += wave_sums[k];
-        total += wave_sums[k];
-    }
-    __syncthreads();
-    *block_total = total;
-    return base + inc - v;
-}
-
-__global__ __launch_bounds__(256) void scan_block_sums(const int32_t* __restrict__ count, int64_t n,
-                                                       int32_t* __restrict__ sums) {
-    const int64_t base = (blockIdx.x * 256ll + threadIdx.x) * 4;
-    int v = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (base + k < n) v += count[base + k];
-    int total;
-    block_exclusive_scan(v, &total);
-    if (threadIdx.x == 0) sums[blockIdx.x] = total;
-}
-
-__global__ __launch_bounds__(256) void scan_sums_inplace(int32_t* __restrict__ sums, int64_t n_blocks) {
-    __shared__ int carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int64_t start = 0; start < n_blocks; start += 256) {
-        const int64_t i = start + threadIdx.x;
-        const int v = (i < n_blocks) ? sums[i] : 0;
-        int total;
-        const int ex = block_exclusive_scan(v, &total);
-        const int carry = carry_s;
-        if (i < n_blocks) sums[i] = carry + ex;
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s = carry + total;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) sums[n_blocks] = carry_s;
-}
-
-__global__ __launch_bounds__(256) void scan_finish(const int32_t* __restrict__ count, int64_t n,
-                                                   const int32_t* __restrict__ sums,
-                                                   int32_t* __restrict__ offs, int64_t n_blocks,
-                                                   FrameCounters* counters, unsigned* sticky) {
-    const int64_t base = (blockIdx.x * 256ll + threadIdx.x) * 4;
-    int c[4];
-    int v = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        c[k] = (base + k < n) ? count[base + k] : 0;
-        v += c[k];
-    }
-    int total;
-    int run = block_exclusive_scan(v, &total) + sums[blockIdx.x];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (base + k < n) offs[base + k] = run;
-        run += c[k];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const int grand = sums[n_blocks];
-        offs[n] = grand;
-        if (counters) counters->entries = static_cast<unsigned long long>(grand);
-        if (sticky) atomicMax(sticky, static_cast<unsigned>(grand));  // largest entry total since the host last looked
-    }
-}
-
-void launch_exclusive_scan(hipStream_t s, const int32_t* count, int32_t* offs, int64_t n,
-                           int32_t* scratch, FrameCounters* counters, unsigned* sticky) {
-    if (n <= 0) return;
-    const int64_t n_blocks = (n + 1023) / 1024;
-    hipLaunchKernelGGL(scan_block_sums, dim3(static_cast<unsigned>(n_blocks)), dim3(256), 0, s, count, n, scratch);
-    hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(256), 0, s, scratch, n_blocks);
-    hipLaunchKernelGGL(scan_finish, dim3(static_cast<unsigned>(n_blocks)), dim3(256), 0, s, count, n, scratch,
-                       offs, n_blocks, counters, sticky);
+    hipLaunchKernelGGL(entry_raster, dim3(blocks), dim3(256), 0, s, g, Xtab, Ytab, im, head, first, pool, capacity,
+                       counters, sticky, want_upper);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -547,18 +471,34 @@ __device__ __forceinline__ StepGeometry step_geometry(const CellRegs& cur, doubl
     return g;
 }
 
-// next place the ray enters the grid beyond s_cur (s = z walking down, -z walking up); -1 if none
+// touched once per frame: kept from displacing the cell records in L2 / Infinity Cache
+__device__ __forceinline__ EntryHead load_entry_head(const EntryHead* p) {
+    const long long v = __builtin_nontemporal_load(reinterpret_cast<const long long*>(p));
+    EntryHead h;
+    h.count = static_cast<int32_t>(v);
+    h.chain = static_cast<int32_t>(v >> 32);
+    return h;
+}
+
+// next place the ray enters the grid beyond s_cur (s = z walking down, -z walking up); -1 if none.
+// The pixel's entries are first[lp] and the chain through the overflow pool (entry_raster).
 template <bool kUp>
-__device__ __forceinline__ int next_entry(const Entry* __restrict__ entries, int e0, int e1, double& s_cur) {
+__device__ __forceinline__ int next_entry(const WalkParams& P, size_t lp, EntryHead h, double& s_cur) {
     double s_best = -DBL_MAX;
     int cell = -1;
-    for (int e = e0; e < e1; ++e) {
-        const Entry en = entries[e];
-        const double se = kUp ? -en.z : en.z;
+    const Entry* e = P.entry_first + lp;
+    int hop = h.chain;
+    for (int k = 0; k < h.count; ++k) {  // bounded by the count: a chain cut short by a pool overflow ends at hop 0
+        const double z = e->z;
+        const int c = e->cell;
+        const double se = kUp ? -z : z;
         if (se < s_cur && se > s_best) {
             s_best = se;
-            cell = en.cell;
+            cell = c;
         }
+        if (hop <= 0 || hop > P.pool_capacity) break;
+        e = P.entry_pool + (hop - 1);
+        hop = e->next;
     }
     if (cell >= 0) s_cur = s_best;
     return cell;
@@ -602,7 +542,8 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
     unsigned n_seg = 0, n_step = 0, is_solid = 0, overflow = 0;
     double tau = 0.0, I = 0.0, T = 1.0;
     double x = 0.0, y = 0.0, s_cur = DBL_MAX;
-    int e0 = 0, e1 = 0, cell = -1;
+    EntryHead ent{0, 0};
+    int cell = -1;
     size_t lp = 0;
     float2 result = make_float2(0.f, 0.f);
 
@@ -621,9 +562,8 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
             x = P.Xtab[col];
             y = P.Ytab[global_row_of(im, lrow)];
             // touched once per frame: keep them from displacing the cell records in L2 / Infinity Cache
-            e0 = __builtin_nontemporal_load(P.entry_offs + lp);
-            e1 = __builtin_nontemporal_load(P.entry_offs + lp + 1);
-            if (e1 > e0) cell = next_entry<kUp>(P.entries, e0, e1, s_cur);
+            ent = load_entry_head(P.entry_head + lp);
+            if (ent.count > 0) cell = next_entry<kUp>(P, lp, ent, s_cur);
         }
     }
 
@@ -645,7 +585,7 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
             overflow = 1;
             nb = -1;
         } else if (nb < 0 && !overflow) {
-            nb = next_entry<kUp>(P.entries, e0, e1, s_cur);  // left the grid: re-entry of a non-convex grid?
+            nb = next_entry<kUp>(P, lp, ent, s_cur);  // left the grid: re-entry of a non-convex grid?
         }
 
         // issue the next cell's loads now; the arithmetic below does not depend on them
@@ -693,13 +633,16 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
     const unsigned s_cov = wave_sum_u32(n_seg > 0 ? 1u : 0u);
     const unsigned s_sol = wave_sum_u32(is_solid);
     const unsigned s_ovf = wave_sum_u32(overflow);
+    const unsigned s_ent = wave_sum_u32(static_cast<unsigned>(ent.count));
     if (lane == 0) {
-        if (s_seg) atomicAdd(&P.counters->segments, static_cast<unsigned long long>(s_seg));
-        if (s_step) atomicAdd(&P.counters->steps, static_cast<unsigned long long>(s_step));
-        if (s_cov) atomicAdd(&P.counters->covered, static_cast<unsigned long long>(s_cov));
-        if (s_sol) atomicAdd(&P.counters->solid_pixels, static_cast<unsigned long long>(s_sol));
+        FrameCounters* const fc = P.counters + ((blockIdx.x * 4u + static_cast<unsigned>(threadIdx.x >> 6)) % kCounterShards);
+        if (s_ent) atomicAdd(&fc->entries, static_cast<unsigned long long>(s_ent));
+        if (s_seg) atomicAdd(&fc->segments, static_cast<unsigned long long>(s_seg));
+        if (s_step) atomicAdd(&fc->steps, static_cast<unsigned long long>(s_step));
+        if (s_cov) atomicAdd(&fc->covered, static_cast<unsigned long long>(s_cov));
+        if (s_sol) atomicAdd(&fc->solid_pixels, static_cast<unsigned long long>(s_sol));
         if (s_ovf) {
-            atomicAdd(&P.counters->walk_overflow, s_ovf);
+            atomicAdd(&fc->walk_overflow, s_ovf);
             atomicAdd(P.sticky + 1, s_ovf);
         }
     }
@@ -848,7 +791,8 @@ __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
     unsigned n_step_wave = 0;  // wave-uniform: lane-steps taken by the whole wavefront
     double tau = 0.0, I = 0.0, T = 1.0;
     double x = 0.0, y = 0.0, s_cur = DBL_MAX;
-    int e0 = 0, e1 = 0, nb = -1;
+    EntryHead ent{0, 0};
+    int nb = -1;
     size_t lp = 0;
     float2 result = make_float2(0.f, 0.f);
 
@@ -866,9 +810,8 @@ __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
             x = P.Xtab[col];
             y = P.Ytab[global_row_of(im, lrow)];
             // touched once per frame: keep them from displacing the cell records in L2 / Infinity Cache
-            e0 = __builtin_nontemporal_load(P.entry_offs + lp);
-            e1 = __builtin_nontemporal_load(P.entry_offs + lp + 1);
-            if (e1 > e0) nb = next_entry<kUp>(P.entries, e0, e1, s_cur);
+            ent = load_entry_head(P.entry_head + lp);
+            if (ent.count > 0) nb = next_entry<kUp>(P, lp, ent, s_cur);
         }
     }
 
@@ -1000,7 +943,7 @@ __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
             int nxt = static_cast<int>(id);
             if (id == kNoCell) {  // left the grid: re-entry of a non-convex grid?
                 if (sg.has_exit) s_cur = fmin(s_cur, sg.s_exit);
-                nxt = next_entry<kUp>(P.entries, e0, e1, s_cur);
+                nxt = next_entry<kUp>(P, lp, ent, s_cur);
             }
             nb = nxt;
         }
@@ -1045,13 +988,16 @@ __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
     const unsigned s_cov = wave_sum_u32(n_seg > 0 ? 1u : 0u);
     const unsigned s_sol = wave_sum_u32(is_solid);
     const unsigned s_ovf = wave_sum_u32(overflow);
+    const unsigned s_ent = wave_sum_u32(static_cast<unsigned>(ent.count));
     if (lane == 0) {
-        if (s_seg) atomicAdd(&P.counters->segments, static_cast<unsigned long long>(s_seg));
-        if (n_step_wave) atomicAdd(&P.counters->steps, static_cast<unsigned long long>(n_step_wave));
-        if (s_cov) atomicAdd(&P.counters->covered, static_cast<unsigned long long>(s_cov));
-        if (s_sol) atomicAdd(&P.counters->solid_pixels, static_cast<unsigned long long>(s_sol));
+        FrameCounters* const fc = P.counters + ((blockIdx.x * 4u + static_cast<unsigned>(wave)) % kCounterShards);
+        if (s_ent) atomicAdd(&fc->entries, static_cast<unsigned long long>(s_ent));
+        if (s_seg) atomicAdd(&fc->segments, static_cast<unsigned long long>(s_seg));
+        if (n_step_wave) atomicAdd(&fc->steps, static_cast<unsigned long long>(n_step_wave));
+        if (s_cov) atomicAdd(&fc->covered, static_cast<unsigned long long>(s_cov));
+        if (s_sol) atomicAdd(&fc->solid_pixels, static_cast<unsigned long long>(s_sol));
         if (s_ovf) {
-            atomicAdd(&P.counters->walk_overflow, s_ovf);
+            atomicAdd(&fc->walk_overflow, s_ovf);
             atomicAdd(P.sticky + 1, s_ovf);
         }
     }
