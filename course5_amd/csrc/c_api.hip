@@ -113,7 +113,7 @@ struct c5_context {
     // options
     double alpha_limit = 2.5;
     double t_cutoff = 1e-12;
-    int tile_shape = 0;
+    int tile_shape = 2;  // 8x8 pixels per wavefront: fewest distinct cells per step
     int xcd_mode = 1;
     int lds_pad = 0;
     int order = 0;

@@ -664,7 +664,17 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
 // The global loads of step k+1 are issued as soon as the exit face of step k is known and are in
 // flight during step k's exp/divide work, as in the direct kernel.
 // ------------------------------------------------------------------------------------------
-constexpr int kStageSlots = 32;   // runs of equal cell ids staged per wavefront and step (more: direct loads)
+#ifndef C5_ELECT_LEADERS
+#define C5_ELECT_LEADERS 1
+#endif
+constexpr bool kElectLeaders = C5_ELECT_LEADERS != 0;  // 0: slots per run of equal ids along the lanes (the older scheme)
+#ifndef C5_STAGE_SLOTS
+#define C5_STAGE_SLOTS 32
+#endif
+#ifndef C5_WALK_WAVES
+#define C5_WALK_WAVES 5
+#endif
+constexpr int kStageSlots = C5_STAGE_SLOTS;   // runs of equal cell ids staged per wavefront and step (more: direct loads)
 // One staged cell in LDS, 16-byte units: 8 of CellRecord, 2 of CellOptics, 1 pad.  176 bytes = 44 banks:
 // sixteen consecutive slots start on sixteen different 16-byte bank columns, so a ds_read_b128 whose
 // 16-lane groups span up to 16 different slots is conflict-free (MI355X_MICROARCH.md, LDS table).
@@ -749,11 +759,12 @@ __device__ unsigned long long g_walk_stamps[16];
 #endif
 
 template <int TILE, int ORDER>
-__global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
+__global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkParams P) {
     using TS = TileShape<TILE>;
     constexpr int TW = TS::WW * TS::GX, TH = TS::WH * TS::GY;
     constexpr bool kUp = (ORDER == 0);
     __shared__ V2 s_stage[4][kStageSlots * kSlotStride];
+    __shared__ int s_elect[4][192];  // per wavefront: two 64-bucket leader tables + the cell id of every slot
 
     const ImageParams& im = P.im;
     const int tiles_x = (im.res_x + TW - 1) / TW;
@@ -781,6 +792,8 @@ __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
     const int lrow = ty * TH + (wave / TS::GX) * TS::WH + (lane / TS::WW);
     const bool in_image = (col < im.res_x) && (lrow < im.n_local_rows);
     V2* const my_stage = s_stage[wave];
+    int* const my_elect = s_elect[wave];
+    my_elect[128 + lane] = 0;  // slot ids: always a valid cell id, whatever the slot's state
     // records and optics are addressed as a uniform base + a 32-bit byte offset per lane (the host
     // only picks this kernel while n_cells * 128 fits 32 bits): one shift-or per load instead of a
     // 64-bit shift and a 64-bit add
@@ -836,6 +849,7 @@ __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
     // against malformed grids (never spin) is one scalar compare per iteration.
 #if C5_WALK_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned stat_runs = 0, stat_distinct = 0, stat_iters = 0, stat_lanes = 0;
     unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
     const unsigned long long t_begin_ = t_prev_;
 #endif
@@ -849,37 +863,96 @@ __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
         }
         n_step_wave += static_cast<unsigned>(__popcll(needs));
 
-        // 1. runs of equal cell ids -> slots.  `left` = nb of the lane to the left (DPP wave shift, one
-        //    VALU instruction, no LDS round trip); lane 0 reads 0 and is a head by decree.
-        const int left = __builtin_amdgcn_mov_dpp(nb, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
-        const unsigned long long heads = (__builtin_amdgcn_ballot_w64(left != nb) | 1ull) & needs;
-        const int n_runs = __popcll(heads);
-        // slot = (heads at or below this lane) - 1, as mbcnt over heads >> 1 seeded with (bit 0) - 1
-        const unsigned long long hs = heads >> 1;
-        const int slot = static_cast<int>(__builtin_amdgcn_mbcnt_hi(
-            static_cast<uint32_t>(hs >> 32),
-            __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hs), static_cast<uint32_t>(static_cast<int>(heads & 1ull) - 1))));
+        // 1. lanes in the same cell -> one slot.
+        int n_runs, slot;
+        if (kElectLeaders) {
+            // Neighbouring rays drift out of phase, so equal ids are rarely ADJACENT along the lanes: the C3
+            // frame has 22-27 runs of equal ids per step but only 7-17 distinct cells (8 in a 16x4 tile).
+            // Elect one leader per distinct cell through a 64-bucket table in LDS: every walking lane
+            // writes its lane id to bucket hash(id), reads the bucket's winner back and compares ids with
+            // it.  All lanes of a cell hash alike, so they follow the winner together or stay unresolved
+            // together (bucket shared with another cell); the unresolved go through a second table with
+            // another hash, and whoever is left after that leads itself.
+            const unsigned unb = static_cast<unsigned>(nb);
+            const unsigned h1 = (unb ^ (unb >> 6)) & 63u;
+            if (need) my_elect[h1] = lane;
+            __builtin_amdgcn_wave_barrier();
+            int w = my_elect[h1];  // lanes without a ray read some old winner: harmless, they match nothing
+            __builtin_amdgcn_wave_barrier();
+            const int id_w = __builtin_amdgcn_ds_bpermute(w << 2, nb);
+            const bool open = need && (id_w != nb);
+            if ((__builtin_amdgcn_ballot_w64(id_w != nb) & needs) != 0ull) {  // wave-uniform; about one step in three
+                const unsigned t = unb >> 6;
+                const unsigned h2 = (unb + t + (t << 2) + (unb >> 12)) & 63u;
+                if (open) my_elect[64 + h2] = lane;
+                __builtin_amdgcn_wave_barrier();
+                const int w2 = my_elect[64 + h2];
+                __builtin_amdgcn_wave_barrier();
+                const int id_w2 = __builtin_amdgcn_ds_bpermute(w2 << 2, nb);
+                if (open) w = (id_w2 == nb) ? w2 : lane;
+            }
+            const unsigned long long heads = __builtin_amdgcn_ballot_w64(w == lane) & needs;
+            n_runs = __popcll(heads);
+            // a leader's slot = leaders below it.  The leaders post their cell id for the loader lanes
+            // (my_elect[128 + slot]; slots not in use keep an older, still valid id) while everybody
+            // fetches its leader's slot.
+            const int rank = static_cast<int>(__builtin_amdgcn_mbcnt_hi(
+                static_cast<uint32_t>(heads >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(heads), 0u)));
+            if (need && w == lane) my_elect[128 + rank] = nb;
+            slot = __builtin_amdgcn_ds_bpermute(w << 2, rank);
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            // runs of equal ids along the lanes.  `left` = nb of the lane to the left (DPP wave shift, one
+            // VALU instruction, no LDS round trip); lane 0 reads 0 and is a head by decree.
+            const int left = __builtin_amdgcn_mov_dpp(nb, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+            const unsigned long long heads = (__builtin_amdgcn_ballot_w64(left != nb) | 1ull) & needs;
+            n_runs = __popcll(heads);
+            // slot = (heads at or below this lane) - 1, as mbcnt over heads >> 1 seeded with (bit 0) - 1
+            const unsigned long long hs = heads >> 1;
+            slot = static_cast<int>(__builtin_amdgcn_mbcnt_hi(
+                static_cast<uint32_t>(hs >> 32),
+                __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hs), static_cast<uint32_t>(static_cast<int>(heads & 1ull) - 1))));
+        }
         const int n_staged = n_runs < kStageSlots ? n_runs : kStageSlots;
-        // lane s learns the cell id of slot s: every lane of a run pushes the same id to lane `slot`
-        // (finished rays push to lane 63, which is a slot only when all 64 lanes are heads).  Lanes
+#if C5_WALK_STAMPS
+        {   // coherence statistics: runs of equal ids against distinct ids among the walking lanes
+            unsigned long long seen = 0ull;  // lanes whose id already occurred in a lower lane
+            for (int l = 0; l < 64; ++l) {
+                const int v = __builtin_amdgcn_readlane(nb, l);
+                if (v < 0) continue;
+                seen |= __builtin_amdgcn_ballot_w64(nb == v && lane > l);
+            }
+            stat_runs += static_cast<unsigned>(n_runs);
+            stat_distinct += static_cast<unsigned>(__popcll(needs & ~seen));
+            stat_iters += 1u;
+            stat_lanes += static_cast<unsigned>(__popcll(needs));
+        }
+#endif
+        // lane s learns the cell id of slot s: every lane of a group pushes the same id to lane `slot`
+        // (finished rays push to lane 63, which is a slot only when all 64 lanes are leaders).  Lanes
         // nobody pushes to read 0 (ds_permute_b32 clears its buffer first; probed on gfx950,
         // scripts/probes/lane_ops_probe.hip): cell 0's record, loaded and never used.
-        const int id_of_lane = __builtin_amdgcn_ds_permute(need ? (slot << 2) : 252, nb);
-#if C5_WALK_STAMPS
-        asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(id_of_lane));
-        C5_STAMP(0);  // runs -> slots, ds_permute landed
-#endif
+        const int id_of_lane = kElectLeaders ? 0 : __builtin_amdgcn_ds_permute(need ? (slot << 2) : 252, nb);
+        C5_STAMP(0);  // lanes -> slots
         // 2. cooperative loads into registers: kPasses passes of 8 slots (8 lanes x 16 B per record)
         //    + one pass for the optics (2 lanes per slot).  Measured on the C3 frame (same GPU): 24
         //    slots 1.31 ms, 32 slots 1.24 ms, 40 slots 1.38 ms and 48 slots 1.31 ms (registers); a
         //    second staging round instead of the direct-load fallback 1.41 ms.
-        V2 stage_r[kPasses];
+        //    A pass none of whose slots is in use is skipped (wave-uniform branch).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
+#pragma clang diagnostic ignored "-Wconditional-uninitialized"
+        V2 stage_r[kPasses];  // a skipped pass leaves its register undefined; it is never stored either
+#pragma clang diagnostic pop
 #pragma unroll
         for (int pass = 0; pass < kPasses; ++pass) {  // fully unrolled: stage_r[] stays in registers
-            const uint32_t id_ = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(sub4 + 32 * pass, id_of_lane));
-            stage_r[pass] = *reinterpret_cast<const V2*>(rec_bytes + ((id_ << 7) | rec_piece_off));
+            if (pass == 0 || 8 * pass < n_staged) {
+                const uint32_t id_ = static_cast<uint32_t>(
+                    kElectLeaders ? my_elect[128 + 8 * pass + sub] : __builtin_amdgcn_ds_bpermute(sub4 + 32 * pass, id_of_lane));
+                stage_r[pass] = *reinterpret_cast<const V2*>(rec_bytes + ((id_ << 7) | rec_piece_off));
+            }
         }
-        const uint32_t ido = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(so4, id_of_lane));
+        const uint32_t ido = static_cast<uint32_t>(kElectLeaders ? my_elect[128 + so] : __builtin_amdgcn_ds_bpermute(so4, id_of_lane));
         const V2 stage_o0 = *reinterpret_cast<const V2*>(opt_bytes + ((ido << 5) | opt_piece_off));
         C5_STAMP(1);  // bpermutes landed, five loads issued
 
@@ -923,15 +996,18 @@ __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
                 cur.r5 = as_d2(r[5]);
                 cur.r6 = as_d2(r[6]);
                 cur.r7 = as_d2(r[7]);
+                // the optics ride along, straight into the pending registers: those are free here (the
+                // previous step's emission is done) and only looked at again if this step contributes
+                pend_o0 = r[8];
+                pend_o1 = r[9];
             } else {
                 load_cell(cur, P.rec, P.opt, nb);  // more distinct cells than slots: rare
+                pend_o0 = V2{cur.o0.a, cur.o0.b};
+                pend_o1 = V2{cur.o1.a, cur.o1.b};
             }
 
             const StepGeometry sg = step_geometry_fast<kUp>(cur, x, y);
             if (sg.contributes) {
-                // the optics are only needed now: straight into the pending registers
-                pend_o0 = staged ? r[8] : V2{cur.o0.a, cur.o0.b};
-                pend_o1 = staged ? r[9] : V2{cur.o1.a, cur.o1.b};
                 ++n_seg;
                 tau = fma(sg.dz, pend_o0.x, tau);  // line.cpp:189 (unclamped alpha); order-independent, done now
                 pend = true;
@@ -957,6 +1033,10 @@ __global__ __launch_bounds__(256, 5) void walk_composite_lds(WalkParams P) {
         for (int k = 0; k < 5; ++k) atomicAdd(&g_walk_stamps[k], stamp_acc[k]);
         atomicAdd(&g_walk_stamps[8], __builtin_amdgcn_s_memtime() - t_begin_);  // whole loop
         atomicAdd(&g_walk_stamps[9], 1ull);                                      // wavefronts
+        atomicAdd(&g_walk_stamps[10], static_cast<unsigned long long>(stat_runs));
+        atomicAdd(&g_walk_stamps[11], static_cast<unsigned long long>(stat_distinct));
+        atomicAdd(&g_walk_stamps[12], static_cast<unsigned long long>(stat_iters));
+        atomicAdd(&g_walk_stamps[13], static_cast<unsigned long long>(stat_lanes));
     }
 #endif
     if (pend) {  // the last step's contribution

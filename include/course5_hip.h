@@ -150,7 +150,7 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  and synchronises inside c5_render_device.
  *   "lds_stage"    1 (default): walk_composite_lds — per step a wavefront loads each distinct cell
  *                  record once and stages it through LDS; 0: every lane loads its own record.
- *   "tile"         wavefront tile: 0 = 64x1 row tile, 1 = 16x4, 2 = 8x8 pixels.
+ *   "tile"         wavefront tile: 0 = 64x1 row tile, 1 = 16x4, 2 = 8x8 pixels (default).
  *   "xcd_mode"     1 (default): 32-row bands dealt round-robin to the 8 XCDs; 0: row-major tiles.
  *   "overlap_setup" 1: entry lists and solid mask are built on a side stream while build_records
  *                  runs (only when "stage_timing" is 0).  Default 0: measured no faster.

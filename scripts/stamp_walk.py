@@ -15,6 +15,17 @@ buf = (C.c_ulonglong * 16)()
 for i in range(3):
     ctx.render()
 lib.c5_debug_walk_stamps(buf, 1)
+for tile in (0, 1, 2):
+    ctx.set_option("tile", tile)
+    ctx.render()
+    ctx.render()
+    lib.c5_debug_walk_stamps(buf, 1)
+    ctx.render()
+    lib.c5_debug_walk_stamps(buf, 1)
+    w = list(buf)
+    it = max(w[12], 1)
+    print(f"tile {tile}: iterations {w[12]}  walking lanes/iter {w[13] / it:.1f}  runs/iter {w[10] / it:.1f}  distinct cells/iter {w[11] / it:.1f}")
+ctx.set_option("tile", 0)
 ctx.render()
 st = ctx.stats()
 lib.c5_debug_walk_stamps(buf, 1)
