@@ -668,11 +668,14 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
 #define C5_ELECT_LEADERS 1
 #endif
 constexpr bool kElectLeaders = C5_ELECT_LEADERS != 0;  // 0: slots per run of equal ids along the lanes (the older scheme)
+// Measured on the C3 frame at 8x8 tiles (7 distinct cells per step on average): 16 slots / 6 wavefronts
+// per SIMD 0.663 ms; 32 slots 0.753 (LDS then caps the CU at 5 workgroups); 8 slots 0.735 (direct-load
+// fallback too often); 7 wavefronts per SIMD (72 VGPRs, 14 spilled) 0.662.
 #ifndef C5_STAGE_SLOTS
-#define C5_STAGE_SLOTS 32
+#define C5_STAGE_SLOTS 16
 #endif
 #ifndef C5_WALK_WAVES
-#define C5_WALK_WAVES 5
+#define C5_WALK_WAVES 6
 #endif
 constexpr int kStageSlots = C5_STAGE_SLOTS;   // runs of equal cell ids staged per wavefront and step (more: direct loads)
 // One staged cell in LDS, 16-byte units: 8 of CellRecord, 2 of CellOptics, 1 pad.  176 bytes = 44 banks:
@@ -765,6 +768,7 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
     constexpr bool kUp = (ORDER == 0);
     __shared__ V2 s_stage[4][kStageSlots * kSlotStride];
     __shared__ int s_elect[4][192];  // per wavefront: two 64-bucket leader tables + the cell id of every slot
+    __shared__ double s_scur[4][64];
 
     const ImageParams& im = P.im;
     const int tiles_x = (im.res_x + TW - 1) / TW;
@@ -787,12 +791,18 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
         if (ty >= tiles_y) return;
     }
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = tx * TW + (wave % TS::GX) * TS::WW + (lane % TS::WW);
-    const int lrow = ty * TH + (wave / TS::GX) * TS::WH + (lane / TS::WW);
-    const bool in_image = (col < im.res_x) && (lrow < im.n_local_rows);
+    // Registers are what caps the resident wavefronts here, so per-lane state the steps do not need
+    // (pixel index, entry head, solid colour, s_cur) is NOT carried through the loop: it is recomputed
+    // or re-read on the rare paths that want it (start, re-entry, end).
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: LDS bases stay scalar
+    auto pixel_col = [&]() { return tx * TW + (wave % TS::GX) * TS::WW + (lane % TS::WW); };
+    auto pixel_lrow = [&]() { return ty * TH + (wave / TS::GX) * TS::WH + (lane / TS::WW); };
+    auto pixel_index = [&]() { return static_cast<size_t>(pixel_lrow()) * im.res_x + pixel_col(); };
+    const bool in_image = (pixel_col() < im.res_x) && (pixel_lrow() < im.n_local_rows);
     V2* const my_stage = s_stage[wave];
     int* const my_elect = s_elect[wave];
+    double* const my_scur = s_scur[wave];  // s_cur of every lane: only read and written around (re-)entries
     my_elect[128 + lane] = 0;  // slot ids: always a valid cell id, whatever the slot's state
     // records and optics are addressed as a uniform base + a 32-bit byte offset per lane (the host
     // only picks this kernel while n_cells * 128 fits 32 bits): one shift-or per load instead of a
@@ -800,31 +810,24 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
     const char* const rec_bytes = reinterpret_cast<const char*>(P.rec);
     const char* const opt_bytes = reinterpret_cast<const char*>(P.opt);
 
-    unsigned n_seg = 0, is_solid = 0, overflow = 0;
+    constexpr unsigned kOverflowBit = 0x80000000u;  // of n_seg: the ray hit the step bound
+    unsigned n_seg = 0;
     unsigned n_step_wave = 0;  // wave-uniform: lane-steps taken by the whole wavefront
     double tau = 0.0, I = 0.0, T = 1.0;
-    double x = 0.0, y = 0.0, s_cur = DBL_MAX;
-    EntryHead ent{0, 0};
+    double x = 0.0, y = 0.0;
     int nb = -1;
-    size_t lp = 0;
-    float2 result = make_float2(0.f, 0.f);
 
     if (in_image) {
-        lp = static_cast<size_t>(lrow) * im.res_x + col;
+        const size_t lp = pixel_index();
         const uint32_t mv = P.mask ? P.mask[lp] : 0u;
-        if (mv) {
-            double colour = 0.0;
-            for (int s = 0; s < P.solids.n_slots; ++s)
-                if (mv == static_cast<uint32_t>(s) + 1u) colour = P.solids.colour[s];
-            result.x = static_cast<float>(colour);
-            result.y = result.x;
-            is_solid = 1;
-        } else {
-            x = P.Xtab[col];
-            y = P.Ytab[global_row_of(im, lrow)];
+        if (!mv) {  // (a solid-marked pixel is written at the end, without a walk)
+            x = P.Xtab[pixel_col()];
+            y = P.Ytab[global_row_of(im, pixel_lrow())];
             // touched once per frame: keep them from displacing the cell records in L2 / Infinity Cache
-            ent = load_entry_head(P.entry_head + lp);
+            const EntryHead ent = load_entry_head(P.entry_head + lp);
+            double s_cur = DBL_MAX;
             if (ent.count > 0) nb = next_entry<kUp>(P, lp, ent, s_cur);
+            my_scur[lane] = s_cur;
         }
     }
 
@@ -858,7 +861,7 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
         const unsigned long long needs = __builtin_amdgcn_ballot_w64(need);
         if (needs == 0ull) break;
         if (iter >= P.max_steps) {
-            if (need) overflow = 1;
+            if (need) n_seg |= kOverflowBit;
             break;
         }
         n_step_wave += static_cast<unsigned>(__popcll(needs));
@@ -1018,8 +1021,11 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
             const uint32_t id = sg.w_out & kIdMask;
             int nxt = static_cast<int>(id);
             if (id == kNoCell) {  // left the grid: re-entry of a non-convex grid?
+                const size_t lp = pixel_index();
+                double s_cur = my_scur[lane];
                 if (sg.has_exit) s_cur = fmin(s_cur, sg.s_exit);
-                nxt = next_entry<kUp>(P, lp, ent, s_cur);
+                nxt = next_entry<kUp>(P, lp, load_entry_head(P.entry_head + lp), s_cur);
+                my_scur[lane] = s_cur;
             }
             nb = nxt;
         }
@@ -1049,16 +1055,29 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
         }
     }
 
+    const unsigned overflow = n_seg >> 31;
+    n_seg &= ~kOverflowBit;
+    unsigned is_solid = 0, n_entries = 0;
     if (in_image) {
-        if (!is_solid) {
-            result.x = static_cast<float>(tau);  // plane.cpp:165
-            result.y = static_cast<float>(I);    // plane.cpp:166
+        const size_t lp = pixel_index();
+        float2 result = make_float2(static_cast<float>(tau), static_cast<float>(I));  // plane.cpp:165-166
+        const uint32_t mv = P.mask ? P.mask[lp] : 0u;
+        if (mv) {
+            double colour = 0.0;
+            for (int s = 0; s < P.solids.n_slots; ++s)
+                if (mv == static_cast<uint32_t>(s) + 1u) colour = P.solids.colour[s];
+            result.x = static_cast<float>(colour);
+            result.y = result.x;
+            is_solid = 1;
+        } else {
+            n_entries = static_cast<unsigned>(load_entry_head(P.entry_head + lp).count);
         }
         __builtin_nontemporal_store(result.x, &P.out[lp].x);
         __builtin_nontemporal_store(result.y, &P.out[lp].y);
     }
 
     if (P.row_cost) {
+        const int lrow = pixel_lrow();
         unsigned rs = n_seg;
 #pragma unroll
         for (int d = TS::WW / 2; d >= 1; d >>= 1) rs += __shfl_xor(rs, d);
@@ -1068,7 +1087,7 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
     const unsigned s_cov = wave_sum_u32(n_seg > 0 ? 1u : 0u);
     const unsigned s_sol = wave_sum_u32(is_solid);
     const unsigned s_ovf = wave_sum_u32(overflow);
-    const unsigned s_ent = wave_sum_u32(static_cast<unsigned>(ent.count));
+    const unsigned s_ent = wave_sum_u32(n_entries);
     if (lane == 0) {
         FrameCounters* const fc = P.counters + ((blockIdx.x * 4u + static_cast<unsigned>(wave)) % kCounterShards);
         if (s_ent) atomicAdd(&fc->entries, static_cast<unsigned long long>(s_ent));
