@@ -68,6 +68,7 @@ constexpr size_t kCountersBytes = sizeof(c5::FrameCounters) * c5::kCounterShards
 struct FrameSlot {
     DeviceBuffer vx, vy, vz, rec, opt, count, head, first, pool, mask, counters, row_cost;
     int64_t entry_capacity = 0;
+    bool head_clean = false;  // the per-pixel entry heads are all zero (the walk kernels leave them so)
     c5::FrameCounters* host_counters = nullptr;  // pinned
     hipEvent_t setup_done = nullptr, walk_done = nullptr;
     bool walk_recorded = false;
@@ -204,6 +205,7 @@ int ensure_image_buffers(c5_context* ctx) {
         FrameSlot& fs = ctx->slots[k];
         C5_HIP(ctx, fs.count.ensure(static_cast<size_t>(padded + 1024) * sizeof(int32_t)));
         C5_HIP(ctx, fs.head.ensure(static_cast<size_t>(padded) * sizeof(c5::EntryHead)));
+        fs.head_clean = false;
         C5_HIP(ctx, fs.first.ensure(static_cast<size_t>(padded) * sizeof(c5::Entry)));
         C5_HIP(ctx, fs.mask.ensure(static_cast<size_t>(padded) * sizeof(uint32_t)));
         C5_HIP(ctx, fs.row_cost.ensure(static_cast<size_t>(im.n_local_rows + 64) * sizeof(uint32_t)));
@@ -373,7 +375,8 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     c5::launch_build_records(s, g, ctx->alpha_limit, ctx->order);
     C5_HIP(ctx, mark(2, s));
     // boundary entries: one raster pass (per-pixel count + first entry + overflow chain)
-    C5_HIP(ctx, hipMemsetAsync(fs.head.ptr, 0, static_cast<size_t>(padded) * sizeof(c5::EntryHead), e));
+    if (!fs.head_clean) C5_HIP(ctx, hipMemsetAsync(fs.head.ptr, 0, static_cast<size_t>(padded) * sizeof(c5::EntryHead), e));
+    fs.head_clean = false;
     if (g.n_cells > 0) {
         c5::launch_entry_lists(e, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im, fs.head.as<c5::EntryHead>(),
                                fs.first.as<c5::Entry>(), fs.pool.as<c5::Entry>(), fs.entry_capacity,
@@ -440,6 +443,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
         C5_HIP(ctx, hipEventRecord(ctx->walk_a[ev_slot], main_s));
     }
     c5::launch_walk(main_s, wp, ctx->tile_shape);
+    fs.head_clean = true;  // stream order: every pixel's head is zero again once the walk has run
     if (ev_slot >= 0) C5_HIP(ctx, hipEventRecord(ctx->walk_b[ev_slot], main_s));
     C5_HIP(ctx, mark(5, main_s));
     C5_HIP(ctx, hipGetLastError());

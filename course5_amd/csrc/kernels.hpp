@@ -27,7 +27,7 @@ struct GridView {  // device pointers of the persistent grid + per-view buffers
 struct WalkParams {
     const CellRecord* rec;
     const CellOptics* opt;
-    const EntryHead* entry_head; // [n_local_px] entries of the pixel + overflow chain
+    EntryHead* entry_head;      // [n_local_px] entries of the pixel + overflow chain; the walk hands it back zeroed
     const Entry* entry_first;   // [n_local_px] first entry (valid where entry_count > 0)
     const Entry* entry_pool;    // overflow entries, chained from entry_first[].next
     int64_t pool_capacity;

@@ -58,9 +58,62 @@ __device__ __forceinline__ FacePlane face_plane(const double (&p)[4][3], int f) 
     return r;
 }
 
+__device__ __forceinline__ bool build_cell_impl(const GridView& g, double alpha_limit, int order, int64_t cell,
+                                                CellRecord& r, CellOptics& o);
+__device__ __forceinline__ bool build_cell(const GridView& g, double alpha_limit, int order, int64_t cell, CellRecord& r,
+                                           CellOptics& o) {
+    return build_cell_impl(g, alpha_limit, order, cell, r, o);
+}
+
+// One thread builds one cell's records in registers; a wavefront then writes its 64 records through a
+// wave-private LDS area so that every store instruction covers 1 KiB of consecutive addresses (a
+// thread storing its own 128-byte record would touch 64 different lines per instruction).
+struct alignas(16) Q4 {
+    uint32_t a, b, c, d;
+};
+constexpr int kRecPad = 9;  // 16-byte units per record in LDS: 8 + 1 pad (conflict-free b128 rows)
+constexpr int kOptPad = 3;  // 2 + 1 pad
+
 __global__ __launch_bounds__(256) void build_records(GridView g, double alpha_limit, int order) {
+    __shared__ Q4 s_rec[4][64 * kRecPad];
+    __shared__ Q4 s_opt[4][64 * kOptPad];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t cell = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
-    if (cell >= g.n_cells) return;
+    const int64_t wave_first = cell - lane;
+    bool valid = cell < g.n_cells;
+    CellRecord r;
+    CellOptics o;
+    if (valid) valid = build_cell(g, alpha_limit, order, cell, r, o);
+    const unsigned long long valid_mask = __builtin_amdgcn_ballot_w64(valid);
+    if (valid_mask == 0ull) return;  // wave-uniform
+    Q4* const my_rec = s_rec[wave];
+    Q4* const my_opt = s_opt[wave];
+    if (valid) {
+        const Q4* rp = reinterpret_cast<const Q4*>(&r);
+        const Q4* op = reinterpret_cast<const Q4*>(&o);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) my_rec[lane * kRecPad + k] = rp[k];
+        my_opt[lane * kOptPad] = op[0];
+        my_opt[lane * kOptPad + 1] = op[1];
+    }
+    __builtin_amdgcn_wave_barrier();
+    Q4* const rec_out = reinterpret_cast<Q4*>(g.rec + wave_first);
+    Q4* const opt_out = reinterpret_cast<Q4*>(g.opt + wave_first);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {  // 8 x 1 KiB: records 8k .. 8k+7 of the wavefront
+        const int rec_i = k * 8 + (lane >> 3);
+        if ((valid_mask >> rec_i) & 1ull) rec_out[k * 64 + lane] = my_rec[rec_i * kRecPad + (lane & 7)];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {  // 2 x 1 KiB of optics
+        const int opt_i = k * 32 + (lane >> 1);
+        if ((valid_mask >> opt_i) & 1ull) opt_out[k * 64 + lane] = my_opt[opt_i * kOptPad + (lane & 1)];
+    }
+}
+
+// Records of one cell; false if the cell is outside this context's row band (nothing to store).
+__device__ __forceinline__ bool build_cell_impl(const GridView& g, double alpha_limit, int order, int64_t cell,
+                                                CellRecord& r, CellOptics& o) {
     const int4 cv = g.cell_vert[cell];
     const int vid[4] = {cv.x, cv.y, cv.z, cv.w};
     double p[4][3];
@@ -70,7 +123,7 @@ __global__ __launch_bounds__(256) void build_records(GridView g, double alpha_li
     // rest (their records are never read).  This is what shards the per-view setup across ranks.
     const double cy_lo = fmin(fmin(p[0][1], p[1][1]), fmin(p[2][1], p[3][1]));
     const double cy_hi = fmax(fmax(p[0][1], p[1][1]), fmax(p[2][1], p[3][1]));
-    if (cy_hi < g.cull_y_lo || cy_lo > g.cull_y_hi) return;
+    if (cy_hi < g.cull_y_lo || cy_lo > g.cull_y_hi) return false;
     const int4 adj = g.cell_adj[cell];
     const int nb[4] = {adj.x, adj.y, adj.z, adj.w};
 #pragma unroll
@@ -93,7 +146,6 @@ __global__ __launch_bounds__(256) void build_records(GridView g, double alpha_li
     const bool flat = (n_lo == 0) || (n_true_up == 0);
 
     // walk order: upper (and edge-on) faces first, lower faces last; everything selected, nothing indexed
-    CellRecord r;
     r.x0 = p[0][0];
     r.y0 = p[0][1];
     int up_pos = 0, lo_pos = n_up;
@@ -145,14 +197,12 @@ __global__ __launch_bounds__(256) void build_records(GridView g, double alpha_li
         r.nbr[j] = words[j];
     }
     r.nbr[0] |= static_cast<uint32_t>(stored_up) << kUpperCountShift;
-    g.rec[cell] = r;
 
     // line.cpp:204-224
     const double a_raw = g.alpha[cell];
     const double qv = g.q[cell];
     double a_c = a_raw;
     if (a_c > alpha_limit) a_c = alpha_limit;
-    CellOptics o;
     o.alpha_raw = a_raw;
     o.q = qv;
     if (a_c < DBL_EPSILON) {
@@ -162,7 +212,7 @@ __global__ __launch_bounds__(256) void build_records(GridView g, double alpha_li
         o.alpha_c = a_c;
         o.aux = (order == 0) ? 1.0 / a_c : qv / a_c;
     }
-    g.opt[cell] = o;
+    return true;
 }
 
 void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, int order) {
@@ -244,62 +294,103 @@ __global__ __launch_bounds__(256) void entry_raster(GridView g, const double* __
     const int r0 = max(static_cast<int>(fmax(fr0, 0.0)), im.row_begin);
     const int r1 = min(static_cast<int>(fmin(fr1, im.res_y - 1.0)), im.row_begin + im.row_count - 1);
     if (r1 < r0) return;
-    const int bw = c1 - c0 + 1;
-    const int64_t n_box = static_cast<int64_t>(bw) * (r1 - r0 + 1);
+    const unsigned bw = static_cast<unsigned>(c1 - c0 + 1);
+    const unsigned n_box = bw * static_cast<unsigned>(r1 - r0 + 1);  // <= pixels of the image: fits 32 bits
 
     const double x0 = p[0][0], y0 = p[0][1];
     const double pc = fp.c, pgx = fp.gx, pgy = fp.gy;
 
-    for (int64_t base = 0; base < n_box; base += 64) {
-        const int64_t idx = base + lane;
-        bool in = false;
-        size_t lp = 0;
-        double x = 0.0, y = 0.0;
-        if (idx < n_box) {
-            const int row = r0 + static_cast<int>(idx / bw);
-            const int col = c0 + static_cast<int>(idx % bw);
-            const int lrow = local_row_of(im, row);
-            if (lrow >= 0) {
-                x = Xtab[col];
-                y = Ytab[row];
-                // closed point-in-triangle test, either winding
-                const double e0 = (bx - ax) * (y - ay) - (by - ay) * (x - ax);
-                const double e1 = (cx - bx) * (y - by) - (cy - by) * (x - bx);
-                const double e2 = (ax - cx) * (y - cy) - (ay - cy) * (x - cx);
-                in = (e0 >= 0 && e1 >= 0 && e2 >= 0) || (e0 <= 0 && e1 <= 0 && e2 <= 0);
-                lp = static_cast<size_t>(lrow) * im.res_x + col;
+    // The raster is bound by vector instructions (the box of a face holds 2.5x the pixels of the face), so
+    // the per-pixel work is kept small: the three edge functions as planes about vertex a (two fused
+    // multiply-adds each; which of two faces claims a pixel within rounding of their common edge was never
+    // defined by the older product form either) and the row / column split by a float reciprocal with a
+    // one-step correction instead of an integer division.
+    const double ea0 = -(by - ay), eb0 = bx - ax;                       // edge a -> b
+    const double ea1 = -(cy - by), eb1 = cx - bx;                       // edge b -> c
+    const double ec1 = -(ea1 * (bx - ax) + eb1 * (by - ay));
+    const double ea2 = -(ay - cy), eb2 = ax - cx;                       // edge c -> a
+    const double ec2 = -(ea2 * (cx - ax) + eb2 * (cy - ay));
+    const float inv_bw = 1.0f / static_cast<float>(bw);
+    const bool small_box = n_box < (1u << 24);  // float(idx) exact: the estimate is off by one at most
+    // Four 64-pixel chunks of the box per iteration: their four returning atomics are in flight together.
+    constexpr int kChunks = 4;
+    for (unsigned base = 0; base < n_box; base += 64u * kChunks) {
+        bool in[kChunks];
+        size_t lp[kChunks];
+        double z[kChunks];
+        int old[kChunks];
+#pragma unroll
+        for (int k = 0; k < kChunks; ++k) {
+            const unsigned idx = base + 64u * k + static_cast<unsigned>(lane);
+            in[k] = false;
+            lp[k] = 0;
+            z[k] = 0.0;
+            if (idx < n_box) {
+                unsigned qrow, rcol;
+                if (small_box) {
+                    qrow = static_cast<unsigned>(static_cast<float>(idx) * inv_bw);
+                    int rem = static_cast<int>(idx - qrow * bw);
+                    if (rem < 0) {
+                        qrow -= 1u;
+                        rem += static_cast<int>(bw);
+                    } else if (rem >= static_cast<int>(bw)) {
+                        qrow += 1u;
+                        rem -= static_cast<int>(bw);
+                    }
+                    rcol = static_cast<unsigned>(rem);
+                } else {
+                    qrow = idx / bw;
+                    rcol = idx - qrow * bw;
+                }
+                const int row = r0 + static_cast<int>(qrow);
+                const int col = c0 + static_cast<int>(rcol);
+                const int lrow = local_row_of(im, row);
+                if (lrow >= 0) {
+                    const double x = Xtab[col], y = Ytab[row];
+                    // closed point-in-triangle test, either winding
+                    const double dxa = x - ax, dya = y - ay;
+                    const double e0 = fma(ea0, dxa, eb0 * dya);
+                    const double e1 = fma(ea1, dxa, fma(eb1, dya, ec1));
+                    const double e2 = fma(ea2, dxa, fma(eb2, dya, ec2));
+                    in[k] = (e0 >= 0 && e1 >= 0 && e2 >= 0) || (e0 <= 0 && e1 <= 0 && e2 <= 0);
+                    lp[k] = static_cast<size_t>(lrow) * im.res_x + col;
+                    z[k] = pc + pgx * (x - x0) + pgy * (y - y0);
+                }
             }
         }
-        const double z = pc + pgx * (x - x0) + pgy * (y - y0);
-        const int old = in ? atomicAdd(&head[lp].count, 1) : 0;
-        if (in && old == 0) {
-            Entry e;
-            e.z = z;
-            e.cell = static_cast<int32_t>(cell);
-            e.next = 0;
-            first[lp] = e;
-        }
-        // further entries: one pool allocation per wavefront and iteration (same-address atomics serialise)
-        const bool more = in && old > 0;
-        const unsigned long long more_mask = __builtin_amdgcn_ballot_w64(more);
-        if (more_mask == 0ull) continue;
-        unsigned pool_base = 0;
-        if (lane == __builtin_ctzll(more_mask))
-            pool_base = atomicAdd(&counters->pool_used, static_cast<unsigned>(__popcll(more_mask)));
-        pool_base = __builtin_amdgcn_readlane(pool_base, __builtin_ctzll(more_mask));
-        if (more) {
-            const unsigned slot = pool_base + static_cast<unsigned>(__popcll(more_mask & ((1ull << lane) - 1ull)));
-            if (static_cast<int64_t>(slot) < capacity) {
+#pragma unroll
+        for (int k = 0; k < kChunks; ++k) old[k] = in[k] ? atomicAdd(&head[lp[k]].count, 1) : 0;
+#pragma unroll
+        for (int k = 0; k < kChunks; ++k) {
+            if (in[k] && old[k] == 0) {
                 Entry e;
-                e.z = z;
+                e.z = z[k];
                 e.cell = static_cast<int32_t>(cell);
-                e.next = atomicExch(&head[lp].chain, static_cast<int32_t>(slot) + 1);
-                pool[slot] = e;
-            } else {
-                // pool too small: the host sees the demand in sticky[0], grows the pool and renders again
-                // (the walk bounds-checks every hop, so this frame is merely wrong, never unsafe)
-                atomicOr(&counters->entry_overflow, 1u);
-                atomicMax(sticky, slot + 1u);
+                e.next = 0;
+                first[lp[k]] = e;
+            }
+            // further entries: one pool allocation per wavefront and chunk (same-address atomics serialise)
+            const bool more = in[k] && old[k] > 0;
+            const unsigned long long more_mask = __builtin_amdgcn_ballot_w64(more);
+            if (more_mask == 0ull) continue;
+            unsigned pool_base = 0;
+            if (lane == __builtin_ctzll(more_mask))
+                pool_base = atomicAdd(&counters->pool_used, static_cast<unsigned>(__popcll(more_mask)));
+            pool_base = __builtin_amdgcn_readlane(pool_base, __builtin_ctzll(more_mask));
+            if (more) {
+                const unsigned slot = pool_base + static_cast<unsigned>(__popcll(more_mask & ((1ull << lane) - 1ull)));
+                if (static_cast<int64_t>(slot) < capacity) {
+                    Entry e;
+                    e.z = z[k];
+                    e.cell = static_cast<int32_t>(cell);
+                    e.next = atomicExch(&head[lp[k]].chain, static_cast<int32_t>(slot) + 1);
+                    pool[slot] = e;
+                } else {
+                    // pool too small: the host sees the demand in sticky[0], grows the pool and renders again
+                    // (the walk bounds-checks every hop, so this frame is merely wrong, never unsafe)
+                    atomicOr(&counters->entry_overflow, 1u);
+                    atomicMax(sticky, slot + 1u);
+                }
             }
         }
     }
@@ -614,6 +705,7 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
             result.x = static_cast<float>(tau);  // plane.cpp:165
             result.y = static_cast<float>(I);    // plane.cpp:166
         }
+        __builtin_nontemporal_store(0ll, reinterpret_cast<long long*>(P.entry_head + lp));  // cleared for the next frame
         __builtin_nontemporal_store(result.x, &P.out[lp].x);
         __builtin_nontemporal_store(result.y, &P.out[lp].y);
     }
@@ -1069,9 +1161,10 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
             result.x = static_cast<float>(colour);
             result.y = result.x;
             is_solid = 1;
-        } else {
-            n_entries = static_cast<unsigned>(load_entry_head(P.entry_head + lp).count);
         }
+        // every pixel hands its entry head back cleared: the next frame's raster needs no memset
+        n_entries = static_cast<unsigned>(load_entry_head(P.entry_head + lp).count);
+        __builtin_nontemporal_store(0ll, reinterpret_cast<long long*>(P.entry_head + lp));
         __builtin_nontemporal_store(result.x, &P.out[lp].x);
         __builtin_nontemporal_store(result.y, &P.out[lp].y);
     }
