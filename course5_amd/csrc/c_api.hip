@@ -912,6 +912,14 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
         ctx->lds_stage = static_cast<int>(value) != 0;
     } else if (n == "integration") {
         ctx->order = static_cast<int>(value) != 0;
+    } else if (n == "entry_pool") {  // testing: (re)size the overflow pool of the entry lists, in records
+        if (value < 1 || value > 16777214) return fail(ctx, C5_ERR_INVALID, "entry_pool out of range");
+        int rc = drain(ctx);
+        if (rc) return rc;
+        for (FrameSlot& fs : ctx->slots) {
+            fs.entry_capacity = static_cast<int64_t>(value);
+            C5_HIP(ctx, fs.pool.ensure(static_cast<size_t>(fs.entry_capacity) * sizeof(c5::Entry)));
+        }
     } else if (n == "lds_pad") {  // tuning: occupancy experiments (scripts/occupancy_sweep.py)
         if (value < 0 || value > 96 * 1024) return fail(ctx, C5_ERR_INVALID, "lds_pad out of range");
         ctx->lds_pad = static_cast<int>(value);

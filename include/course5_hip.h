@@ -157,6 +157,9 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *   "pipeline"     1: two frame slots; the per-view setup of frame k + 1 runs on a second stream while
  *                  frame k is walked (set before c5_upload_grid / c5_set_image).  Default 0: on
  *                  MI355X the walk already fills the GPU and the overlap measured slower.
+ *   "entry_pool"   testing: size of the overflow pool of the per-pixel entry lists, in records (it holds
+ *                  the second and further entries of a ray; it grows by itself through C5_RETRY).
+ *   "lds_pad"      tuning: extra dynamic LDS per workgroup in bytes, to cap the resident wavefronts.
  *   "row_costs"    1: walk_composite also accumulates segments per image row (c5_get_row_costs).
  *   "stage_timing" / "walk_timing"  0/1: record HIP events per stage / around walk_composite. */
 int c5_set_option(c5_context* ctx, const char* name, double value);
