@@ -20,7 +20,9 @@ GROUPS_=(
   "TCP_TCC_READ_REQ_sum TCP_TA_TCP_STATE_READ_sum"
 )
 rm -rf "$OUT"/pmc_* "$OUT"/prof_kt
-rocprofv3 --kernel-trace --stats -d "$OUT/prof_kt" -o kt --output-format csv -- "${CMD[@]}" > "$OUT/prof_kt.log" 2>&1 || exit 1
+# the kernel trace runs the SAME command as the bench line (default steps / warmup), so that its average
+# kernel duration and bench.py's HIP-event figure describe the same sustained state
+rocprofv3 --kernel-trace --stats -d "$OUT/prof_kt" -o kt --output-format csv -- python3 bench.py --no-cpu-baseline > "$OUT/prof_kt.log" 2>&1 || exit 1
 for g in "${GROUPS_[@]}"; do
   name="pmc_${g%% *}"
   # shellcheck disable=SC2086
