@@ -118,6 +118,33 @@ __host__ __device__ inline int local_row_of(const ImageParams& im, int row) {
     if (tile % im.world != im.rank) return -1;
     return (tile / im.world) * im.tile_rows + (r - tile * im.tile_rows);
 }
+// Local rows whose global row lies in [g0, g1] (both inside [row_begin, row_begin + row_count)) form one
+// range of consecutive LOCAL indices, because local rows are numbered in global order: its first and
+// last index, first > last if there is none.  Lets the entry raster enumerate only this context's rows.
+__host__ __device__ inline void local_row_span(const ImageParams& im, int g0, int g1, int& first, int& last) {
+    const int a = g0 - im.row_begin, b = g1 - im.row_begin;
+    if (im.world == 1) {
+        first = a;
+        last = b;
+        return;
+    }
+    // first local row at or after a
+    const int ta = a / im.tile_rows;
+    const int skip_a = ((im.rank - ta % im.world) + im.world) % im.world;  // tiles to the next one of this rank
+    first = (skip_a == 0) ? (ta / im.world) * im.tile_rows + (a - ta * im.tile_rows)
+                          : ((ta + skip_a) / im.world) * im.tile_rows;
+    // last local row at or before b
+    const int tb = b / im.tile_rows;
+    const int back_b = ((tb % im.world - im.rank) + im.world) % im.world;  // tiles back to the previous one of this rank
+    if (back_b == 0) {
+        last = (tb / im.world) * im.tile_rows + (b - tb * im.tile_rows);
+    } else if (tb - back_b < 0) {
+        last = -1;
+    } else {
+        last = ((tb - back_b) / im.world) * im.tile_rows + im.tile_rows - 1;
+    }
+    if (last > im.n_local_rows - 1) last = im.n_local_rows - 1;
+}
 // local row -> global row
 __host__ __device__ inline int global_row_of(const ImageParams& im, int lrow) {
     if (im.world == 1) return im.row_begin + lrow;

@@ -294,8 +294,12 @@ __global__ __launch_bounds__(256) void entry_raster(GridView g, const double* __
     const int r0 = max(static_cast<int>(fmax(fr0, 0.0)), im.row_begin);
     const int r1 = min(static_cast<int>(fmin(fr1, im.res_y - 1.0)), im.row_begin + im.row_count - 1);
     if (r1 < r0) return;
+    // only the rows of this context (cyclic row tiles: every world-th tile), as a range of LOCAL rows
+    int lr0, lr1;
+    local_row_span(im, r0, r1, lr0, lr1);
+    if (lr1 < lr0) return;
     const unsigned bw = static_cast<unsigned>(c1 - c0 + 1);
-    const unsigned n_box = bw * static_cast<unsigned>(r1 - r0 + 1);  // <= pixels of the image: fits 32 bits
+    const unsigned n_box = bw * static_cast<unsigned>(lr1 - lr0 + 1);  // <= pixels of the image: fits 32 bits
 
     const double x0 = p[0][0], y0 = p[0][1];
     const double pc = fp.c, pgx = fp.gx, pgy = fp.gy;
@@ -342,10 +346,10 @@ __global__ __launch_bounds__(256) void entry_raster(GridView g, const double* __
                     qrow = idx / bw;
                     rcol = idx - qrow * bw;
                 }
-                const int row = r0 + static_cast<int>(qrow);
+                const int lrow = lr0 + static_cast<int>(qrow);
+                const int row = global_row_of(im, lrow);
                 const int col = c0 + static_cast<int>(rcol);
-                const int lrow = local_row_of(im, row);
-                if (lrow >= 0) {
+                {
                     const double x = Xtab[col], y = Ytab[row];
                     // closed point-in-triangle test, either winding
                     const double dxa = x - ax, dya = y - ay;

@@ -40,7 +40,7 @@ for world in (2, 4, 8):
           "walk", [round(p["ms_walk"], 3) for p in per])
     per = []
     for r in range(world):
-        ctx.set_row_tiles(16, r, world)
+        ctx.set_row_tiles(int(os.environ.get("TILE_ROWS", "16")), r, world)
         per.append(timed())
     ctx.set_row_tiles(0, 0, 1)
     tot = [round(p["ms_total"], 3) for p in per]

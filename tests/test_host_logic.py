@@ -1,4 +1,6 @@
 """Host-side logic: synthetic grids, row-tile sharding, view rotation list.  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -95,3 +97,15 @@ def test_balanced_blocks_degenerate_inputs():
     blocks = sharding.balanced_blocks(np.arange(12), 3)
     strips = [np.vstack([full[b:b + n], np.zeros((2, 3, 2), np.float32)]) for b, n in blocks]
     assert np.array_equal(sharding.assemble_blocks(strips, blocks, 12), full)
+
+
+def test_local_row_span_matches_brute_force(tmp_path):
+    """device_types.hpp: local_row_span (the entry raster enumerates only a context's own rows with it)
+    against local_row_of / global_row_of by brute force over worlds, ranks, tile heights and row ranges."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "row_span_check"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "course5_amd", "csrc"),
+                    os.path.join(root, "tests", "cpp", "row_span_check.cpp"), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert out.startswith("ok "), out
