@@ -899,7 +899,6 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
     V2* const my_stage = s_stage[wave];
     int* const my_elect = s_elect[wave];
     double* const my_scur = s_scur[wave];  // s_cur of every lane: only read and written around (re-)entries
-    my_elect[128 + lane] = 0;  // slot ids: always a valid cell id, whatever the slot's state
     // records and optics are addressed as a uniform base + a 32-bit byte offset per lane (the host
     // only picks this kernel while n_cells * 128 fits 32 bits): one shift-or per load instead of a
     // 64-bit shift and a 64-bit add
@@ -913,19 +912,35 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
     double x = 0.0, y = 0.0;
     int nb = -1;
 
-    if (in_image) {
-        const size_t lp = pixel_index();
-        const uint32_t mv = P.mask ? P.mask[lp] : 0u;
-        if (!mv) {  // (a solid-marked pixel is written at the end, without a walk)
+    {
+        // Most wavefronts of a frame see neither the grid nor a solid (70 % on the C3 frame): they store
+        // their zeros and leave at once (their entry heads are zero already).  An empty pixel used to
+        // cost as much as six ray-cell segments.
+        size_t lp = 0;
+        uint32_t mv = 0;
+        EntryHead ent{0, 0};
+        if (in_image) {
+            lp = pixel_index();
+            mv = P.mask ? P.mask[lp] : 0u;
+            // touched once per frame: keep them from displacing the cell records in L2 / Infinity Cache
+            ent = load_entry_head(P.entry_head + lp);
+        }
+        if (__builtin_amdgcn_ballot_w64(mv != 0u || ent.count != 0) == 0ull) {
+            if (in_image) {
+                __builtin_nontemporal_store(0.f, &P.out[lp].x);
+                __builtin_nontemporal_store(0.f, &P.out[lp].y);
+            }
+            return;
+        }
+        if (in_image && !mv) {  // (a solid-marked pixel is written at the end, without a walk)
             x = P.Xtab[pixel_col()];
             y = P.Ytab[global_row_of(im, pixel_lrow())];
-            // touched once per frame: keep them from displacing the cell records in L2 / Infinity Cache
-            const EntryHead ent = load_entry_head(P.entry_head + lp);
             double s_cur = DBL_MAX;
             if (ent.count > 0) nb = next_entry<kUp>(P, lp, ent, s_cur);
             my_scur[lane] = s_cur;
         }
     }
+    my_elect[128 + lane] = 0;  // slot ids: always a valid cell id, whatever the slot's state
 
     // contribution of the step whose record is being replaced (integrated while the next loads fly)
     // (optics kept as the two 16-byte halves they are read in: {alpha_raw, alpha_c}, {aux, q})
@@ -1168,7 +1183,7 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
         }
         // every pixel hands its entry head back cleared: the next frame's raster needs no memset
         n_entries = static_cast<unsigned>(load_entry_head(P.entry_head + lp).count);
-        __builtin_nontemporal_store(0ll, reinterpret_cast<long long*>(P.entry_head + lp));
+        if (n_entries) __builtin_nontemporal_store(0ll, reinterpret_cast<long long*>(P.entry_head + lp));
         __builtin_nontemporal_store(result.x, &P.out[lp].x);
         __builtin_nontemporal_store(result.y, &P.out[lp].y);
     }
