@@ -117,6 +117,7 @@ struct c5_context {
     int tile_shape = 2;  // 8x8 pixels per wavefront: fewest distinct cells per step
     int xcd_mode = 1;
     int lds_pad = 0;
+    int band_rows = 0;
     int order = 0;
     int lds_stage = 1;
     int stage_timing = 1;
@@ -412,6 +413,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     wp.max_steps = static_cast<uint32_t>(ctx->n_cells + 64);
     wp.xcd_mode = ctx->xcd_mode;
     wp.lds_pad = ctx->lds_pad;
+    wp.band_rows = ctx->band_rows;
     wp.order = ctx->order;
     // walk_composite_lds addresses the records by 32-bit byte offsets: n_cells * 128 must fit
     wp.lds_stage = (ctx->lds_stage && ctx->n_cells < (int64_t{1} << 25)) ? 1 : 0;
@@ -920,6 +922,9 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
             fs.entry_capacity = static_cast<int64_t>(value);
             C5_HIP(ctx, fs.pool.ensure(static_cast<size_t>(fs.entry_capacity) * sizeof(c5::Entry)));
         }
+    } else if (n == "band_rows") {  // tuning: image rows per XCD band of the walk (0: default 32)
+        if (value < 0 || value > 4096) return fail(ctx, C5_ERR_INVALID, "band_rows out of range");
+        ctx->band_rows = static_cast<int>(value);
     } else if (n == "lds_pad") {  // tuning: occupancy experiments (scripts/occupancy_sweep.py)
         if (value < 0 || value > 96 * 1024) return fail(ctx, C5_ERR_INVALID, "lds_pad out of range");
         ctx->lds_pad = static_cast<int>(value);
