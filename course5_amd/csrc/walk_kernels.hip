@@ -377,13 +377,18 @@ __global__ __launch_bounds__(256) void entry_raster(GridView g, const double* __
             const bool more = in[k] && old[k] > 0;
             const unsigned long long more_mask = __builtin_amdgcn_ballot_w64(more);
             if (more_mask == 0ull) continue;
+            // (the pool is cut into kCounterShards equal parts, each with its counter on a line of its own:
+            // a non-convex grid makes tens of thousands of these allocations per frame)
+            const unsigned shard = static_cast<unsigned>(face_idx) % kCounterShards;
+            const unsigned shard_cap = static_cast<unsigned>(capacity / kCounterShards);
             unsigned pool_base = 0;
             if (lane == __builtin_ctzll(more_mask))
-                pool_base = atomicAdd(&counters->pool_used, static_cast<unsigned>(__popcll(more_mask)));
+                pool_base = atomicAdd(&counters[shard].pool_used, static_cast<unsigned>(__popcll(more_mask)));
             pool_base = __builtin_amdgcn_readlane(pool_base, __builtin_ctzll(more_mask));
             if (more) {
-                const unsigned slot = pool_base + static_cast<unsigned>(__popcll(more_mask & ((1ull << lane) - 1ull)));
-                if (static_cast<int64_t>(slot) < capacity) {
+                const unsigned local = pool_base + static_cast<unsigned>(__popcll(more_mask & ((1ull << lane) - 1ull)));
+                const unsigned slot = shard * shard_cap + local;
+                if (local < shard_cap) {
                     Entry e;
                     e.z = z[k];
                     e.cell = static_cast<int32_t>(cell);
@@ -392,8 +397,9 @@ __global__ __launch_bounds__(256) void entry_raster(GridView g, const double* __
                 } else {
                     // pool too small: the host sees the demand in sticky[0], grows the pool and renders again
                     // (the walk bounds-checks every hop, so this frame is merely wrong, never unsafe)
+                    // demand: as if every shard were as full as this one
                     atomicOr(&counters->entry_overflow, 1u);
-                    atomicMax(sticky, slot + 1u);
+                    atomicMax(sticky, (local + 1u) * kCounterShards);
                 }
             }
         }
