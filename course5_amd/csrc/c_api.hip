@@ -132,6 +132,7 @@ struct c5_context {
 
     bool using_caller_stream = false;
     bool frame_pending = false;
+    bool counters_on_host = true;  // the last frame's counters / sticky words have been copied to the host
     bool frame_timed = false;
     c5_stats last{};
 };
@@ -285,6 +286,7 @@ int enqueue_bin_sort(c5_context* ctx, FrameSlot& fs, const c5::GridView& g, int 
     C5_HIP(ctx, hipMemcpyAsync(fs.host_counters, fs.counters.ptr, kCountersBytes, hipMemcpyDeviceToHost, s));
     C5_HIP(ctx, hipMemcpyAsync(ctx->host_sticky, ctx->sticky.ptr, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     C5_HIP(ctx, hipStreamSynchronize(s));
+    ctx->counters_on_host = true;
     fs.host_counters->segments = static_cast<unsigned long long>(total);
     if (ctx->pipeline) {  // keep the two-stream bookkeeping consistent
         C5_HIP(ctx, hipEventRecord(fs.setup_done, s));
@@ -327,7 +329,6 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     if (ctx->pipeline && fs.walk_recorded) C5_HIP(ctx, hipStreamWaitEvent(s, fs.walk_done, 0));
 
     C5_HIP(ctx, mark(0, s));
-    C5_HIP(ctx, hipMemsetAsync(fs.counters.ptr, 0, kCountersBytes, s));
 
     c5::GridView g;
     g.n_pts = ctx->n_pts;
@@ -359,7 +360,9 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     }
 
     // (a2) view transform
-    c5::launch_transform_soa(s, g.px, g.py, g.pz, g.vx, g.vy, g.vz, g.n_pts, ctx->view);
+    // (a2) + the frame's statistics cleared by the same launch
+    c5::launch_transform_soa(s, g.px, g.py, g.pz, g.vx, g.vy, g.vz, g.n_pts, ctx->view,
+                             fs.counters.as<c5::FrameCounters>());
     C5_HIP(ctx, mark(1, s));
     const bool bin_sort = ctx->algorithm == 1 || !ctx->grid_conforming;
     if (bin_sort) return enqueue_bin_sort(ctx, fs, g, slot_id, out_dev, s, main_s, timed);
@@ -449,8 +452,9 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     if (ev_slot >= 0) C5_HIP(ctx, hipEventRecord(ctx->walk_b[ev_slot], main_s));
     C5_HIP(ctx, mark(5, main_s));
     C5_HIP(ctx, hipGetLastError());
-    C5_HIP(ctx, hipMemcpyAsync(fs.host_counters, fs.counters.ptr, kCountersBytes, hipMemcpyDeviceToHost, main_s));
-    C5_HIP(ctx, hipMemcpyAsync(ctx->host_sticky, ctx->sticky.ptr, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, main_s));
+    // the statistics of the last frame and the sticky failure words are fetched when somebody waits for
+    // the stream (wait_and_collect), not once per frame: two API calls and two small copies less per frame
+    ctx->counters_on_host = false;
     if (ctx->pipeline) {
         C5_HIP(ctx, hipEventRecord(fs.walk_done, main_s));
         fs.walk_recorded = true;
@@ -460,6 +464,20 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     ctx->frame_pending = true;
     ctx->frame_timed = timed;
     return C5_OK;
+}
+
+int finish_frame(c5_context* ctx);
+
+// Wait for the context's stream and collect the last frame's outcome.
+int wait_and_collect(c5_context* ctx) {
+    if (ctx->frame_pending && !ctx->counters_on_host) {
+        FrameSlot& fs = ctx->slots[ctx->last_slot];
+        C5_HIP(ctx, hipMemcpyAsync(fs.host_counters, fs.counters.ptr, kCountersBytes, hipMemcpyDeviceToHost, ctx->stream));
+        C5_HIP(ctx, hipMemcpyAsync(ctx->host_sticky, ctx->sticky.ptr, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        ctx->counters_on_host = true;
+    }
+    C5_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return finish_frame(ctx);
 }
 
 // After the stream drained: collect counters/timings; grow the entry buffer if it overflowed.
@@ -645,8 +663,7 @@ int c5_set_stream(c5_context* ctx, void* hip_stream) {
     if (!ctx) return fail(nullptr, C5_ERR_INVALID, "null context");
     int rc = bind_device(ctx);
     if (rc) return rc;
-    C5_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    rc = finish_frame(ctx);
+    rc = wait_and_collect(ctx);
     ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
     ctx->using_caller_stream = hip_stream != nullptr;
     return rc == C5_RETRY ? C5_OK : rc;
@@ -952,8 +969,7 @@ int c5_synchronize(c5_context* ctx) {
     if (!ctx) return fail(nullptr, C5_ERR_INVALID, "null context");
     int rc = bind_device(ctx);
     if (rc) return rc;
-    C5_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return finish_frame(ctx);
+    return wait_and_collect(ctx);
 }
 
 int c5_render(c5_context* ctx, float* out_host) {

@@ -34,6 +34,8 @@ __device__ __forceinline__ void rotate_point(const RotationList& R, double& x, d
     }
 }
 
+constexpr int64_t kCountersDwords = static_cast<int64_t>(sizeof(FrameCounters)) * kCounterShards / 4;
+
 // SoA in -> SoA out (volume grid vertices): one thread per vertex, fully coalesced.
 __global__ __launch_bounds__(256) void transform_points_soa(const double* __restrict__ px,
                                                             const double* __restrict__ py,
@@ -41,8 +43,11 @@ __global__ __launch_bounds__(256) void transform_points_soa(const double* __rest
                                                             double* __restrict__ vx,
                                                             double* __restrict__ vy,
                                                             double* __restrict__ vz, int64_t n,
-                                                            RotationList R) {
+                                                            RotationList R, uint32_t* __restrict__ counters) {
     const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    // first kernel of a frame: it also clears the frame's statistics (one API call less per frame than a
+    // memset of its own); the grid covers at least kCountersDwords threads
+    if (counters && i < kCountersDwords) counters[i] = 0u;
     if (i >= n) return;
     double x = px[i], y = py[i], z = pz[i];
     rotate_point(R, x, y, z);
@@ -486,10 +491,13 @@ void launch_resolve(hipStream_t s, const GridView& g, const ImageParams& im, con
 size_t segment_bytes() { return sizeof(Segment); }
 
 void launch_transform_soa(hipStream_t s, const double* px, const double* py, const double* pz,
-                          double* vx, double* vy, double* vz, int64_t n, const RotationList& R) {
-    if (n <= 0) return;
-    const unsigned blocks = static_cast<unsigned>((n + 255) / 256);
-    hipLaunchKernelGGL(transform_points_soa, dim3(blocks), dim3(256), 0, s, px, py, pz, vx, vy, vz, n, R);
+                          double* vx, double* vy, double* vz, int64_t n, const RotationList& R,
+                          FrameCounters* counters_to_clear) {
+    const int64_t threads = counters_to_clear ? (n > kCountersDwords ? n : kCountersDwords) : n;
+    if (threads <= 0) return;
+    const unsigned blocks = static_cast<unsigned>((threads + 255) / 256);
+    hipLaunchKernelGGL(transform_points_soa, dim3(blocks), dim3(256), 0, s, px, py, pz, vx, vy, vz, n, R,
+                       reinterpret_cast<uint32_t*>(counters_to_clear));
 }
 
 void launch_transform_aos(hipStream_t s, const double* in, double* out, int64_t n,

@@ -51,8 +51,10 @@ struct WalkParams {
 };
 
 // exact_kernels.hip (-ffp-contract=off)
+// counters_to_clear: the frame's FrameCounters[kCounterShards], zeroed by the same launch (or nullptr)
 void launch_transform_soa(hipStream_t s, const double* px, const double* py, const double* pz,
-                          double* vx, double* vy, double* vz, int64_t n, const RotationList& R);
+                          double* vx, double* vy, double* vz, int64_t n, const RotationList& R,
+                          FrameCounters* counters_to_clear);
 void launch_transform_aos(hipStream_t s, const double* in, double* out, int64_t n,
                           const RotationList& R);
 void launch_solid_mask_raster(hipStream_t s, const double* pts, const int4* faces, int64_t n_faces,
