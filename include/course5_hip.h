@@ -74,7 +74,7 @@ typedef struct c5_stats {
     /* GPU time of the last frame per stage, milliseconds (HIP events on the context stream) */
     float ms_transform;      /* view transform                     (a2) */
     float ms_records;        /* per-cell walk records              (a1, a10) */
-    float ms_entries;        /* boundary entry raster + scan       (a6/a7 for boundary faces) */
+    float ms_entries;        /* boundary entry raster, one pass    (a6/a7 for boundary faces) */
     float ms_solids;         /* solid mask raster                  (a6, a9) */
     float ms_walk;           /* walk_composite                     (a11-a14) */
     float ms_total;          /* first kernel start -> image complete in HBM */
