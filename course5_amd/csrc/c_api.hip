@@ -3,6 +3,8 @@
 // and leaves a message for c5_last_error().
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -52,6 +54,7 @@ struct Solid {
     int64_t n_points = 0;    // unique points
     int64_t n_faces = 0;     // unique faces
     double colour = 0.0;
+    double typical_edge = 0.0;  // mean over the unique faces of their longest edge (object units)
     DeviceBuffer raw;        // unique points [m][3]
     DeviceBuffer faces;      // unique faces, int4 (a, b, c, 0)
     DeviceBuffer view[2];    // transformed points, one per frame slot
@@ -244,9 +247,13 @@ int enqueue_solids(c5_context* ctx, FrameSlot& fs, int slot_id, hipStream_t s, c
             Solid& so = ctx->solids[k];
             if (so.n_tets <= 0) continue;
             c5::launch_transform_aos(s, so.raw.as<double>(), so.view[slot_id].as<double>(), so.n_points, so.rots);
+            // lanes per face: about one per eight image rows of a typical face, a power of two up to 16
+            const double rows = so.typical_edge / std::fabs(im.step_y);
+            int lanes = 1;
+            while (lanes < 16 && rows > 8.0 * lanes) lanes *= 2;
             c5::launch_solid_mask_raster(s, so.view[slot_id].as<double>(), so.faces.as<int4>(), so.n_faces,
                                          static_cast<uint32_t>(k) + 1u, ctx->ytab.as<double>(), im,
-                                         fs.mask.as<uint32_t>());
+                                         fs.mask.as<uint32_t>(), lanes);
         }
     }
     return C5_OK;
@@ -781,6 +788,19 @@ int c5_set_solid(c5_context* ctx, int slot, const double* tets, int64_t n_tets, 
         c5::unique_solid_faces(tets, n_tets, pts, faces);
         s.n_points = static_cast<int64_t>(pts.size() / 3);
         s.n_faces = static_cast<int64_t>(faces.size() / 4);
+        {   // how tall a face typically is decides how many lanes share one face in solid_mask_raster
+            double sum = 0.0;
+            for (size_t f = 0; f < faces.size() / 4; ++f) {
+                const double* a = &pts[3 * static_cast<size_t>(faces[4 * f])];
+                const double* b = &pts[3 * static_cast<size_t>(faces[4 * f + 1])];
+                const double* c = &pts[3 * static_cast<size_t>(faces[4 * f + 2])];
+                auto d2 = [](const double* u, const double* v) {
+                    return (u[0] - v[0]) * (u[0] - v[0]) + (u[1] - v[1]) * (u[1] - v[1]) + (u[2] - v[2]) * (u[2] - v[2]);
+                };
+                sum += std::sqrt(std::max(d2(a, b), std::max(d2(b, c), d2(a, c))));
+            }
+            s.typical_edge = s.n_faces ? sum / static_cast<double>(s.n_faces) : 0.0;
+        }
         const size_t bytes = pts.size() * sizeof(double);
         C5_HIP(ctx, s.raw.ensure(bytes));
         C5_HIP(ctx, s.faces.ensure(faces.size() * sizeof(int32_t)));

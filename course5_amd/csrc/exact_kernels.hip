@@ -186,22 +186,26 @@ struct FaceScan {
     }
 };
 
-// One thread per UNIQUE solid face (host: unique_solid_faces).  pts: transformed points [m][3].
+// LANES threads per UNIQUE solid face (host: unique_solid_faces), rows of the face dealt among them: the
+// kernel's time is the longest chain of rows one thread walks (the centre-fan slivers of the Roche lobe
+// are hundreds of rows tall at 2400x1800), not its total work.  pts: transformed points [m][3].
 // mask[local pixel] receives the largest (slot + 1) of the solid objects covering it: objects
 // later in the tetra vector overwrite earlier ones in the serial reference (line.cpp:246-249), and
 // all cells of one object share a colour.
 __global__ __launch_bounds__(256) void solid_mask_raster(const double* __restrict__ pts,
                                                          const int4* __restrict__ faces, int64_t n_faces,
                                                          uint32_t value, const double* __restrict__ Ytab,
-                                                         ImageParams im, uint32_t* __restrict__ mask) {
-    const int64_t gid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+                                                         ImageParams im, uint32_t* __restrict__ mask, int lanes_log2) {
+    const int64_t tid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    const int64_t gid = tid >> lanes_log2;
+    const long long sub = static_cast<long long>(tid & ((1ll << lanes_log2) - 1)), n_sub = 1ll << lanes_log2;
     if (gid >= n_faces) return;
     const int4 fc = faces[gid];
     FaceScan fs;
     fs.setup(pts[3 * static_cast<size_t>(fc.x)], pts[3 * static_cast<size_t>(fc.x) + 1],
              pts[3 * static_cast<size_t>(fc.y)], pts[3 * static_cast<size_t>(fc.y) + 1],
              pts[3 * static_cast<size_t>(fc.z)], pts[3 * static_cast<size_t>(fc.z) + 1], im);
-    for (long long row = fs.row_lo; row <= fs.row_hi; ++row) {
+    for (long long row = fs.row_lo + sub; row <= fs.row_hi; row += n_sub) {
         const int lrow = local_row_of(im, static_cast<int>(row));
         if (lrow < 0) continue;
         const double y = Ytab[row];  // == _lines[0][row_lo].y() + k * step_y accumulated (plane.cpp:100,138)
@@ -508,10 +512,15 @@ void launch_transform_aos(hipStream_t s, const double* in, double* out, int64_t 
 }
 
 void launch_solid_mask_raster(hipStream_t s, const double* pts, const int4* faces, int64_t n_faces,
-                              uint32_t value, const double* Ytab, const ImageParams& im, uint32_t* mask) {
+                              uint32_t value, const double* Ytab, const ImageParams& im, uint32_t* mask,
+                              int lanes_per_face) {
     if (n_faces <= 0) return;
-    const unsigned blocks = static_cast<unsigned>((n_faces + 255) / 256);
-    hipLaunchKernelGGL(solid_mask_raster, dim3(blocks), dim3(256), 0, s, pts, faces, n_faces, value, Ytab, im, mask);
+    int lanes_log2 = 0;
+    while ((2 << lanes_log2) <= lanes_per_face && lanes_log2 < 6) ++lanes_log2;
+    const int64_t threads = n_faces << lanes_log2;
+    const unsigned blocks = static_cast<unsigned>((threads + 255) / 256);
+    hipLaunchKernelGGL(solid_mask_raster, dim3(blocks), dim3(256), 0, s, pts, faces, n_faces, value, Ytab, im, mask,
+                       lanes_log2);
 }
 
 }  // namespace c5

@@ -58,7 +58,8 @@ void launch_transform_soa(hipStream_t s, const double* px, const double* py, con
 void launch_transform_aos(hipStream_t s, const double* in, double* out, int64_t n,
                           const RotationList& R);
 void launch_solid_mask_raster(hipStream_t s, const double* pts, const int4* faces, int64_t n_faces,
-                              uint32_t value, const double* Ytab, const ImageParams& im, uint32_t* mask);
+                              uint32_t value, const double* Ytab, const ImageParams& im, uint32_t* mask,
+                              int lanes_per_face);  // power of two, 1..64: threads sharing the rows of one face
 
 // bin-sort-resolve (exact_kernels.hip): the reference's algorithm on the GPU
 void launch_bin_count(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
