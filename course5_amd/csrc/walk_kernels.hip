@@ -989,27 +989,29 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
             // Neighbouring rays drift out of phase, so equal ids are rarely ADJACENT along the lanes: the C3
             // frame has 22-27 runs of equal ids per step but only 7-17 distinct cells (8 in a 16x4 tile).
             // Elect one leader per distinct cell through a 64-bucket table in LDS: every walking lane
-            // writes its lane id to bucket hash(id), reads the bucket's winner back and compares ids with
-            // it.  All lanes of a cell hash alike, so they follow the winner together or stay unresolved
-            // together (bucket shared with another cell); the unresolved go through a second table with
-            // another hash, and whoever is left after that leads itself.
+            // writes (id << 6 | lane) to bucket hash(id) — ids of this kernel have 25 bits — and reads the
+            // bucket's winner back: one LDS round trip tells it the winner's lane AND whether the winner
+            // is in the same cell.  All lanes of a cell hash alike, so they follow the winner together or
+            // stay unresolved together (bucket shared with another cell); the unresolved go through a
+            // second table with another hash, and whoever is left after that leads itself.
             const unsigned unb = static_cast<unsigned>(nb);
             const unsigned h1 = (unb ^ (unb >> 6)) & 63u;
-            if (need) my_elect[h1] = lane;
+            const int ticket = static_cast<int>((unb << 6) | static_cast<unsigned>(lane));
+            if (need) my_elect[h1] = ticket;
             __builtin_amdgcn_wave_barrier();
-            int w = my_elect[h1];  // lanes without a ray read some old winner: harmless, they match nothing
+            const int won = my_elect[h1];  // lanes without a ray read some old ticket: harmless, they match nothing
             __builtin_amdgcn_wave_barrier();
-            const int id_w = __builtin_amdgcn_ds_bpermute(w << 2, nb);
-            const bool open = need && (id_w != nb);
-            if ((__builtin_amdgcn_ballot_w64(id_w != nb) & needs) != 0ull) {  // wave-uniform; about one step in three
+            int w = won & 63;
+            const bool other = (won >> 6) != nb;
+            const bool open = need && other;
+            if ((__builtin_amdgcn_ballot_w64(other) & needs) != 0ull) {  // wave-uniform; about one step in three
                 const unsigned t = unb >> 6;
                 const unsigned h2 = (unb + t + (t << 2) + (unb >> 12)) & 63u;
-                if (open) my_elect[64 + h2] = lane;
+                if (open) my_elect[64 + h2] = ticket;
                 __builtin_amdgcn_wave_barrier();
-                const int w2 = my_elect[64 + h2];
+                const int won2 = my_elect[64 + h2];
                 __builtin_amdgcn_wave_barrier();
-                const int id_w2 = __builtin_amdgcn_ds_bpermute(w2 << 2, nb);
-                if (open) w = (id_w2 == nb) ? w2 : lane;
+                if (open) w = ((won2 >> 6) == nb) ? (won2 & 63) : lane;
             }
             const unsigned long long heads = __builtin_amdgcn_ballot_w64(w == lane) & needs;
             n_runs = __popcll(heads);
