@@ -50,23 +50,44 @@ class FramePipeline:
                                   for r in range(world)]
         self.pending = []
         self.k = 0
+        # Rank 0 reassembles the frame on a stream of its own, beside its next render (the copies are
+        # bandwidth-bound, the walk is not): `assembled[s]` marks when parts[s] may be overwritten again.
+        on_gpu = getattr(device, "type", str(device)) == "cuda"
+        self.side = torch.cuda.Stream(device=device) if (world > 1 and rank == 0 and on_gpu) else None
+        self.assembled = [None] * self.depth
+
+    def _assemble(self, s):
+        for r in range(self.world):
+            if self.blocks is not None:
+                b, n = self.blocks[r]
+                self.frame[b:b + n].copy_(self.parts[s][r][:n])
+            else:
+                idx = self.row_index[r]
+                self.frame.index_copy_(0, idx, self.parts[s][r][: idx.numel()])
 
     def _finish(self, slot):
         work, s = slot
-        work.wait()  # on GPU: the current stream waits for the collective, the host does not
-        if self.rank == 0:
-            for r in range(self.world):
-                if self.blocks is not None:
-                    b, n = self.blocks[r]
-                    self.frame[b:b + n].copy_(self.parts[s][r][:n])
-                else:
-                    idx = self.row_index[r]
-                    self.frame.index_copy_(0, idx, self.parts[s][r][: idx.numel()])
+        if self.side is None:
+            work.wait()  # on GPU: the current stream waits for the collective, the host does not
+            if self.rank == 0:
+                self._assemble(s)
+            return
+        cur = torch.cuda.current_stream()
+        self.side.wait_stream(cur)  # (host-staged rehearsal: the parts were copied in on the current stream)
+        with torch.cuda.stream(self.side):
+            work.wait()  # the side stream waits for the collective
+            self._assemble(s)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self.assembled[s] = ev
 
     def step(self, render):
         """render(strip) must fill strip[:local_rows] (enqueue on the current stream on GPU)."""
         s = self.k % self.depth
         self.k += 1
+        if self.assembled[s] is not None:  # the gather of this step overwrites parts[s]
+            torch.cuda.current_stream().wait_event(self.assembled[s])
+            self.assembled[s] = None
         render(self.strips[s])
         if self.world == 1:
             self.frame = self.strips[s]
@@ -89,6 +110,8 @@ class FramePipeline:
     def drain(self):
         while self.pending:
             self._finish(self.pending.pop(0))
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
         return self.frame
 
 
