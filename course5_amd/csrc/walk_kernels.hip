@@ -779,7 +779,11 @@ constexpr bool kElectLeaders = C5_ELECT_LEADERS != 0;  // 0: slots per run of eq
 #ifndef C5_WALK_WAVES
 #define C5_WALK_WAVES 6
 #endif
-constexpr int kStageSlots = C5_STAGE_SLOTS;   // runs of equal cell ids staged per wavefront and step (more: direct loads)
+constexpr int kStageSlots = C5_STAGE_SLOTS;
+#ifndef C5_ELECT_BUCKETS
+#define C5_ELECT_BUCKETS 256
+#endif
+constexpr unsigned kBuckets1 = C5_ELECT_BUCKETS;  // first leader table (power of two)   // runs of equal cell ids staged per wavefront and step (more: direct loads)
 // One staged cell in LDS, 16-byte units: 8 of CellRecord, 2 of CellOptics, 1 pad.  176 bytes = 44 banks:
 // sixteen consecutive slots start on sixteen different 16-byte bank columns, so a ds_read_b128 whose
 // 16-lane groups span up to 16 different slots is conflict-free (MI355X_MICROARCH.md, LDS table).
@@ -869,7 +873,8 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
     constexpr int TW = TS::WW * TS::GX, TH = TS::WH * TS::GY;
     constexpr bool kUp = (ORDER == 0);
     __shared__ V2 s_stage[4][kStageSlots * kSlotStride];
-    __shared__ int s_elect[4][192];  // per wavefront: two 64-bucket leader tables + the cell id of every slot
+    // per wavefront: leader tables of kBuckets1 and 64 buckets + the cell id of every slot
+    __shared__ int s_elect[4][kBuckets1 + 128];
     __shared__ double s_scur[4][64];
 
     const ImageParams& im = P.im;
@@ -946,7 +951,7 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
             my_scur[lane] = s_cur;
         }
     }
-    my_elect[128 + lane] = 0;  // slot ids: always a valid cell id, whatever the slot's state
+    my_elect[kBuckets1 + 64 + lane] = 0;  // slot ids: always a valid cell id, whatever the slot's state
 
     // contribution of the step whose record is being replaced (integrated while the next loads fly)
     // (optics kept as the two 16-byte halves they are read in: {alpha_raw, alpha_c}, {aux, q})
@@ -988,14 +993,15 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
         if (kElectLeaders) {
             // Neighbouring rays drift out of phase, so equal ids are rarely ADJACENT along the lanes: the C3
             // frame has 22-27 runs of equal ids per step but only 7-17 distinct cells (8 in a 16x4 tile).
-            // Elect one leader per distinct cell through a 64-bucket table in LDS: every walking lane
+            // Elect one leader per distinct cell through a table of kBuckets1 buckets in LDS (7 cells share
+            // a bucket in one step of twelve at 256 buckets, in one of three at 64): every walking lane
             // writes (id << 6 | lane) to bucket hash(id) — ids of this kernel have 25 bits — and reads the
             // bucket's winner back: one LDS round trip tells it the winner's lane AND whether the winner
             // is in the same cell.  All lanes of a cell hash alike, so they follow the winner together or
             // stay unresolved together (bucket shared with another cell); the unresolved go through a
             // second table with another hash, and whoever is left after that leads itself.
             const unsigned unb = static_cast<unsigned>(nb);
-            const unsigned h1 = (unb ^ (unb >> 6)) & 63u;
+            const unsigned h1 = (unb ^ (unb >> 8)) & (kBuckets1 - 1u);
             const int ticket = static_cast<int>((unb << 6) | static_cast<unsigned>(lane));
             if (need) my_elect[h1] = ticket;
             __builtin_amdgcn_wave_barrier();
@@ -1004,23 +1010,23 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
             int w = won & 63;
             const bool other = (won >> 6) != nb;
             const bool open = need && other;
-            if ((__builtin_amdgcn_ballot_w64(other) & needs) != 0ull) {  // wave-uniform; about one step in three
+            if ((__builtin_amdgcn_ballot_w64(other) & needs) != 0ull) {  // wave-uniform; about one step in twelve
                 const unsigned t = unb >> 6;
                 const unsigned h2 = (unb + t + (t << 2) + (unb >> 12)) & 63u;
-                if (open) my_elect[64 + h2] = ticket;
+                if (open) my_elect[kBuckets1 + h2] = ticket;
                 __builtin_amdgcn_wave_barrier();
-                const int won2 = my_elect[64 + h2];
+                const int won2 = my_elect[kBuckets1 + h2];
                 __builtin_amdgcn_wave_barrier();
                 if (open) w = ((won2 >> 6) == nb) ? (won2 & 63) : lane;
             }
             const unsigned long long heads = __builtin_amdgcn_ballot_w64(w == lane) & needs;
             n_runs = __popcll(heads);
             // a leader's slot = leaders below it.  The leaders post their cell id for the loader lanes
-            // (my_elect[128 + slot]; slots not in use keep an older, still valid id) while everybody
+            // (my_elect[kBuckets1 + 64 + slot]; slots not in use keep an older, still valid id) while everybody
             // fetches its leader's slot.
             const int rank = static_cast<int>(__builtin_amdgcn_mbcnt_hi(
                 static_cast<uint32_t>(heads >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(heads), 0u)));
-            if (need && w == lane) my_elect[128 + rank] = nb;
+            if (need && w == lane) my_elect[kBuckets1 + 64 + rank] = nb;
             slot = __builtin_amdgcn_ds_bpermute(w << 2, rank);
             __builtin_amdgcn_wave_barrier();
         } else {
@@ -1070,11 +1076,11 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
         for (int pass = 0; pass < kPasses; ++pass) {  // fully unrolled: stage_r[] stays in registers
             if (pass == 0 || 8 * pass < n_staged) {
                 const uint32_t id_ = static_cast<uint32_t>(
-                    kElectLeaders ? my_elect[128 + 8 * pass + sub] : __builtin_amdgcn_ds_bpermute(sub4 + 32 * pass, id_of_lane));
+                    kElectLeaders ? my_elect[kBuckets1 + 64 + 8 * pass + sub] : __builtin_amdgcn_ds_bpermute(sub4 + 32 * pass, id_of_lane));
                 stage_r[pass] = *reinterpret_cast<const V2*>(rec_bytes + ((id_ << 7) | rec_piece_off));
             }
         }
-        const uint32_t ido = static_cast<uint32_t>(kElectLeaders ? my_elect[128 + so] : __builtin_amdgcn_ds_bpermute(so4, id_of_lane));
+        const uint32_t ido = static_cast<uint32_t>(kElectLeaders ? my_elect[kBuckets1 + 64 + so] : __builtin_amdgcn_ds_bpermute(so4, id_of_lane));
         const V2 stage_o0 = *reinterpret_cast<const V2*>(opt_bytes + ((ido << 5) | opt_piece_off));
         C5_STAMP(1);  // bpermutes landed, five loads issued
 
