@@ -13,16 +13,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _scene_fn():
+def _fuzz():
     spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "scripts", "fuzz_parity.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    return mod.scene
+    return mod
 
 
 @pytest.mark.parametrize("block", range(4))
 def test_random_scenes_match_the_oracle(gpu_ctx, oracle_port, block):
-    scene = _scene_fn()
+    fuzz = _fuzz()
+    scene = fuzz.scene
     gpu_ctx.set_row_tiles(0, 0, 1)
     gpu_ctx.set_row_range(0, -1)
     for k in range(10):
@@ -37,7 +38,7 @@ def test_random_scenes_match_the_oracle(gpu_ctx, oracle_port, block):
         gpu_ctx.set_image(res[0], res[1], mg.REFERENCE_BOUNDS)
         gpu_ctx.set_view(rots)
         gpu_ctx.set_alpha_limit(limit)
-        lds, order, tile = [(1, 0, 0), (0, 0, 1), (1, 1, 2), (0, 1, 0)][k % 4]
+        lds, order, tile = fuzz.VARIANTS[k % len(fuzz.VARIANTS)]
         gpu_ctx.set_option("lds_stage", lds)
         gpu_ctx.set_option("integration", order)
         gpu_ctx.set_option("tile", tile)
@@ -49,5 +50,5 @@ def test_random_scenes_match_the_oracle(gpu_ctx, oracle_port, block):
         assert st["segments"] == ref["segments"] and st["covered_pixels"] == ref["covered"], seed
     gpu_ctx.set_option("lds_stage", 1)
     gpu_ctx.set_option("integration", 0)
-    gpu_ctx.set_option("tile", 0)
+    gpu_ctx.set_option("tile", 2)
     gpu_ctx.set_alpha_limit(2.5)
