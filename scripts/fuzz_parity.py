@@ -70,7 +70,34 @@ def main():
                 print(f"seed {seed} lds {lds} order {order} tile {tile}: {n_bad} px beyond tolerance, "
                       f"S {st['segments']} vs {ref['segments']}, covered {st['covered_pixels']} vs {ref['covered']}, "
                       f"cells {len(cells)} res {res}", flush=True)
-    print(f"{n_scenes} scenes x {len(VARIANTS)} variants: {bad} mismatching renders")
+        # sharded renders of the same scene (what the ranks of a multi-GPU run do), reassembled on the host:
+        # cyclic row tiles and contiguous blocks, random world size and tile height, product-default kernel
+        from course5_amd import sharding
+        rng = np.random.default_rng(seed + 77)
+        ctx.set_option("lds_stage", 1); ctx.set_option("integration", 0); ctx.set_option("tile", 2)
+        ctx.set_row_tiles(0, 0, 1)
+        ctx.set_row_range(0, -1)
+        full = ctx.render()
+        world = int(rng.integers(2, 6))
+        tile_rows = int(rng.choice([1, 3, 8, 16]))
+        strips = []
+        for r in range(world):
+            ctx.set_row_tiles(tile_rows, r, world)
+            strips.append(ctx.render())
+        ctx.set_row_tiles(0, 0, 1)
+        cyc = sharding.assemble(strips, res[1], tile_rows, world)
+        blocks = sharding.equal_blocks(res[1], world)
+        parts = []
+        for b, n_rows in blocks:
+            ctx.set_row_range(b, n_rows)
+            parts.append(ctx.render())
+        ctx.set_row_range(0, -1)
+        blk = np.concatenate(parts, axis=0)
+        for name, img2 in (("cyclic", cyc), ("blocks", blk)):
+            if not np.array_equal(img2.view(np.uint32), full.view(np.uint32)):
+                bad += 1
+                print(f"seed {seed}: {name} shards (world {world}, tile_rows {tile_rows}) differ from the full frame", flush=True)
+    print(f"{n_scenes} scenes x ({len(VARIANTS)} variants + 2 sharded layouts): {bad} mismatching renders")
     return bad
 
 if __name__ == "__main__":
