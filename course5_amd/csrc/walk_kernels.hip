@@ -1019,8 +1019,10 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
                 __builtin_amdgcn_wave_barrier();
                 if (open) w = ((won2 >> 6) == nb) ? (won2 & 63) : lane;
             }
-            const unsigned long long heads = __builtin_amdgcn_ballot_w64(w == lane) & needs;
-            n_runs = __popcll(heads);
+            // (uicmp: the compare straight into a lane mask; ballot() of this bool went through a 0/1 register)
+            const unsigned long long heads =
+                __builtin_amdgcn_uicmp(static_cast<unsigned>(w), static_cast<unsigned>(lane), 32 /* eq */) & needs;
+            n_runs = __builtin_popcountll(heads);
             // a leader's slot = leaders below it.  The leaders post their cell id for the loader lanes
             // (my_elect[kBuckets1 + 64 + slot]; slots not in use keep an older, still valid id) while everybody
             // fetches its leader's slot.
@@ -1041,7 +1043,8 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
                 static_cast<uint32_t>(hs >> 32),
                 __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hs), static_cast<uint32_t>(static_cast<int>(heads & 1ull) - 1))));
         }
-        const int n_staged = n_runs < kStageSlots ? n_runs : kStageSlots;
+        // (kept in a scalar register by hand: as a plain min() the compiler compared it on the vector unit)
+        const int n_staged = __builtin_amdgcn_readfirstlane(n_runs < kStageSlots ? n_runs : kStageSlots);
 #if C5_WALK_STAMPS
         {   // coherence statistics: runs of equal ids against distinct ids among the walking lanes
             unsigned long long seen = 0ull;  // lanes whose id already occurred in a lower lane
