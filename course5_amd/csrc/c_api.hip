@@ -118,7 +118,7 @@ struct c5_context {
     double alpha_limit = 2.5;
     double t_cutoff = 1e-12;
     int tile_shape = 2;  // 8x8 pixels per wavefront: fewest distinct cells per step
-    int xcd_mode = 1;
+    int xcd_mode = 2;
     int lds_pad = 0;
     int band_rows = 0;
     int order = 0;
@@ -966,7 +966,7 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
         if (value < 0 || value > 96 * 1024) return fail(ctx, C5_ERR_INVALID, "lds_pad out of range");
         ctx->lds_pad = static_cast<int>(value);
     } else if (n == "xcd_mode") {
-        ctx->xcd_mode = static_cast<int>(value) != 0;
+        ctx->xcd_mode = static_cast<int>(value) < 0 ? 0 : (static_cast<int>(value) > 2 ? 2 : static_cast<int>(value));
     } else if (n == "row_costs") {
         ctx->row_costs = static_cast<int>(value) != 0;
     } else if (n == "stage_timing") {

@@ -884,6 +884,20 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
     if (P.xcd_mode == 0) {
         ty = blockIdx.x / tiles_x;
         tx = blockIdx.x - ty * tiles_x;
+    } else if (P.xcd_mode == 2) {
+        // square super-blocks of S x S workgroups dealt round-robin to the 8 XCDs: the workgroups an XCD
+        // runs at a time are neighbours in x AND y, so a cell's record is fetched into few L2s
+        const int S = P.band_tiles;
+        const int sbx_n = (tiles_x + S - 1) / S, sby_n = (tiles_y + S - 1) / S;
+        const int xcd = blockIdx.x & 7;
+        const int seq = blockIdx.x >> 3;
+        const int sb = (seq / (S * S)) * 8 + xcd;
+        const int within = seq - (seq / (S * S)) * (S * S);
+        if (sb >= sbx_n * sby_n) return;
+        const int sby = sb / sbx_n, sbx = sb - sby * sbx_n;
+        ty = sby * S + within / S;
+        tx = sbx * S + (within - (within / S) * S);
+        if (tx >= tiles_x || ty >= tiles_y) return;
     } else {
         const int BAND = P.band_tiles;
         const int n_bands = (tiles_y + BAND - 1) / BAND;
@@ -1252,6 +1266,18 @@ static void launch_walk_t(hipStream_t s, const WalkParams& p) {
     long long blocks;
     if (p.xcd_mode == 0) {
         blocks = static_cast<long long>(tiles_x) * tiles_y;
+    } else if (p.xcd_mode == 2 && p.lds_stage) {
+        // measured (C3 grid, 8x8 tiles, walk ms at 1200x900 / 2400x1800 / 4800x3600): super-blocks of 32 rows
+        // 0.303 / 0.601 / 2.070, of 64 rows 0.350 / 0.602 / 2.063; bands of 16 rows 0.310 / 0.610 / 2.065;
+        // row-major blocks 0.372 / 0.597 / 2.059
+        const int sb_rows = p.band_rows > 0 ? p.band_rows : 32;
+        const int S = sb_rows / TH > 0 ? sb_rows / TH : 1;
+        const long long n_sb = static_cast<long long>((tiles_x + S - 1) / S) * ((tiles_y + S - 1) / S);
+        blocks = 8ll * ((n_sb + 7) / 8) * S * S;
+        WalkParams q = p;
+        q.band_tiles = S;
+        hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, q);
+        return;
     } else {
         // ~16 image rows per band (one row of workgroups), but never fewer than 16 bands (2 per XCD) on a short strip
         // measured (C3 grid, 8x8 tiles, walk ms at 1200x900 / 2400x1800 / 4800x3600): row-major blocks

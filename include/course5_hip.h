@@ -151,8 +151,9 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *   "lds_stage"    1 (default): walk_composite_lds — per step a wavefront loads each distinct cell
  *                  record once and stages it through LDS; 0: every lane loads its own record.
  *   "tile"         wavefront tile: 0 = 64x1 row tile, 1 = 16x4, 2 = 8x8 pixels (default).
- *   "xcd_mode"     1 (default): bands of image rows dealt round-robin to the 8 XCDs; 0: row-major tiles.
- *   "band_rows"    tuning: rows per band of "xcd_mode" 1 (0 = default 16).
+ *   "xcd_mode"     how workgroups map to the 8 XCDs (blocks b and b + 8 share an L2): 2 (default): square
+ *                  super-blocks of workgroups dealt round-robin; 1: bands of image rows; 0: row-major tiles.
+ *   "band_rows"    tuning: rows per super-block ("xcd_mode" 2, 0 = default 32) or band (1, default 16).
  *   "overlap_setup" 1: entry lists and solid mask are built on a side stream while build_records
  *                  runs (only when "stage_timing" is 0).  Default 0: measured no faster.
  *   "pipeline"     1: two frame slots; the per-view setup of frame k + 1 runs on a second stream while

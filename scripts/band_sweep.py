@@ -11,7 +11,7 @@ ctx.set_image(res[0], res[1], mg.REFERENCE_BOUNDS)
 ctx.set_view(mg.view_rotations(0.1, 0.07))
 ctx.set_option("stage_timing", 0)
 out = torch.zeros((res[1], res[0], 2), dtype=torch.float32, device="cuda:0")
-for xm, rows in ((0, 0), (1, 16), (1, 32), (1, 64), (1, 128), (1, 256)):
+for xm, rows in ((0, 0), (1, 16), (2, 32), (2, 64), (2, 128), (2, 256)):
     ctx.set_option("xcd_mode", xm)
     ctx.set_option("band_rows", rows)
     for _ in range(30):
