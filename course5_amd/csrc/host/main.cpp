@@ -1,6 +1,9 @@
 // `course` — command line of the MI355X build.  Same options, banner, timing lines, input and
 // output contract as the reference's project/src/main.cpp; the per-pixel OpenMP loops behind
 // `plane` are replaced by the HIP kernels in libcourse5_hip.so.
+#include <omp.h>
+
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <memory>
@@ -58,6 +61,9 @@ int main(int argc, char** argv) try {
     std::cout << "Plane angle around y: " << config.angle_around_y << " Pi" << std::endl;
     std::cout << "Initial system angle around y: " << config.system_initial_angle_around_y << " Pi" << std::endl;
     std::cout << "Limit alpha value: " << config.limit_alpha_value << std::endl;
+
+    // main.cpp:125: -j sizes the OpenMP team of the host-side work (here: adjacency build, .vti writer)
+    omp_set_num_threads(static_cast<int>(std::max<std::size_t>(1, config.threads)));
 
     render_config view = config;  // angles that a sweep advances
     auto apply_view = [&](object3d_base& disk, object3d_base* lobe) {
