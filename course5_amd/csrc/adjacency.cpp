@@ -1,5 +1,7 @@
 #include "adjacency.hpp"
 
+#include <omp.h>
+
 #include <algorithm>
 #include <cstring>
 
@@ -16,6 +18,58 @@ inline bool key_less(const FaceKey& l, const FaceKey& r) {
     return l.c < r.c;
 }
 inline bool key_eq(const FaceKey& l, const FaceKey& r) { return l.a == r.a && l.b == r.b && l.c == r.c; }
+
+// Sort by (a, b, c) on all OpenMP threads: the keys are dealt into buckets by ranges of `a` (their
+// smallest point id, spread evenly over [0, n_ids)), the buckets are sorted independently, and their
+// concatenation is sorted.  (std::sort alone took 250 ms of the 290 ms of c5_upload_grid at 1M cells.)
+template <class Less>
+void sort_keys(std::vector<FaceKey>& keys, uint64_t n_ids, Less less) {
+    const int threads = omp_get_max_threads();
+    if (threads < 2 || keys.size() < (size_t{1} << 16) || n_ids == 0) {
+        std::sort(keys.begin(), keys.end(), less);
+        return;
+    }
+    const int n_buckets = threads * 8;
+    auto bucket_of = [&](const FaceKey& k) {
+        const uint64_t b = static_cast<uint64_t>(k.a) * static_cast<uint64_t>(n_buckets) / n_ids;
+        return static_cast<int>(b < static_cast<uint64_t>(n_buckets) ? b : n_buckets - 1);
+    };
+    const int64_t n = static_cast<int64_t>(keys.size());
+    std::vector<size_t> hist(static_cast<size_t>(threads) * n_buckets, 0);
+    std::vector<FaceKey> tmp(keys.size());
+    std::vector<size_t> start(static_cast<size_t>(n_buckets) + 1, 0);
+#pragma omp parallel num_threads(threads)
+    {
+        const int t = omp_get_thread_num();
+        const int64_t lo = n * t / threads, hi = n * (t + 1) / threads;
+        size_t* mine = hist.data() + static_cast<size_t>(t) * n_buckets;
+        for (int64_t i = lo; i < hi; ++i) ++mine[bucket_of(keys[static_cast<size_t>(i)])];
+#pragma omp barrier
+#pragma omp single
+        {   // bucket b of thread t starts after all of bucket b - 1 and after bucket b of the threads before t
+            size_t run = 0;
+            for (int b = 0; b < n_buckets; ++b) {
+                start[static_cast<size_t>(b)] = run;
+                for (int u = 0; u < threads; ++u) {
+                    const size_t c = hist[static_cast<size_t>(u) * n_buckets + b];
+                    hist[static_cast<size_t>(u) * n_buckets + b] = run;
+                    run += c;
+                }
+            }
+            start[static_cast<size_t>(n_buckets)] = run;
+        }
+        for (int64_t i = lo; i < hi; ++i) {
+            const FaceKey& k = keys[static_cast<size_t>(i)];
+            tmp[mine[bucket_of(k)]++] = k;
+        }
+#pragma omp barrier
+#pragma omp for schedule(dynamic, 1)
+        for (int b = 0; b < n_buckets; ++b)
+            std::sort(tmp.begin() + static_cast<std::ptrdiff_t>(start[static_cast<size_t>(b)]),
+                      tmp.begin() + static_cast<std::ptrdiff_t>(start[static_cast<size_t>(b) + 1]), less);
+    }
+    keys.swap(tmp);
+}
 }  // namespace
 
 bool build_face_adjacency(const int32_t* cell_vert, int64_t n_cells, int64_t n_pts,
@@ -41,7 +95,7 @@ bool build_face_adjacency(const int32_t* cell_vert, int64_t n_cells, int64_t n_p
         err = "cell references a point id out of range";
         return false;
     }
-    std::sort(keys.begin(), keys.end(), key_less);
+    sort_keys(keys, static_cast<uint64_t>(n_pts), key_less);
 
     adj.assign(static_cast<size_t>(4 * n_cells), -1);
     bfaces.clear();

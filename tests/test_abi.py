@@ -71,3 +71,21 @@ def test_create_without_gpu_fails_loudly():
     with pytest.raises(capi.C5Error) as e:
         capi.Context(0)
     assert e.value.code == capi.C5_ERR_NO_DEVICE
+
+
+def test_face_adjacency_of_a_large_grid_matches_numpy():
+    """Large enough for the parallel bucket sort of the face keys (adjacency.cpp: sort_keys)."""
+    xyz, cells = mg.kuhn_box(28, jitter=0.1)   # 131 712 cells, 526 848 face keys
+    adj, n_boundary = capi.face_adjacency(cells, len(xyz))
+    fv = np.array([[0, 1, 2], [0, 1, 3], [0, 2, 3], [1, 2, 3]])
+    faces = np.sort(cells[:, fv].reshape(-1, 3), axis=1)            # [4n, 3], face f of cell c at 4c + f
+    order = np.lexsort((faces[:, 2], faces[:, 1], faces[:, 0]))
+    sf = faces[order]
+    same_next = np.r_[(sf[1:] == sf[:-1]).all(axis=1), False]
+    same_prev = np.r_[False, same_next[:-1]]
+    want = np.full(4 * len(cells), -1, dtype=np.int64)
+    i = np.nonzero(same_next)[0]
+    want[order[i]] = order[i + 1] // 4
+    want[order[i + 1]] = order[i] // 4
+    assert int((~same_next & ~same_prev).sum()) == n_boundary == 6 * 28 * 28 * 2
+    assert np.array_equal(adj.reshape(-1), want)
