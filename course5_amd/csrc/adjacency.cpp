@@ -70,6 +70,39 @@ void sort_keys(std::vector<FaceKey>& keys, uint64_t n_ids, Less less) {
     }
     keys.swap(tmp);
 }
+
+// Comparison sort on all OpenMP threads, for any strict weak order: equal chunks sorted independently,
+// then merged pairwise (the last merges run on few threads, but a merge is a single linear pass).
+template <class T, class Less>
+void parallel_sort(std::vector<T>& v, Less less) {
+    const size_t n = v.size();
+    int parts = 1;
+    while (parts * 2 <= omp_get_max_threads() && parts < 64) parts *= 2;
+    if (parts < 2 || n < (size_t{1} << 16)) {
+        std::sort(v.begin(), v.end(), less);
+        return;
+    }
+    std::vector<size_t> edge(static_cast<size_t>(parts) + 1);
+    for (int p = 0; p <= parts; ++p) edge[static_cast<size_t>(p)] = n * static_cast<size_t>(p) / static_cast<size_t>(parts);
+#pragma omp parallel for schedule(static) num_threads(parts)
+    for (int p = 0; p < parts; ++p)
+        std::sort(v.begin() + static_cast<std::ptrdiff_t>(edge[static_cast<size_t>(p)]),
+                  v.begin() + static_cast<std::ptrdiff_t>(edge[static_cast<size_t>(p) + 1]), less);
+    std::vector<T> other(n);
+    T* src = v.data();
+    T* dst = other.data();
+    for (int width = 1; width < parts; width *= 2) {
+        const int pairs = parts / (2 * width);
+#pragma omp parallel for schedule(static) num_threads(pairs)
+        for (int k = 0; k < pairs; ++k) {
+            const size_t lo = edge[static_cast<size_t>(2 * width * k)], mid = edge[static_cast<size_t>(2 * width * k + width)],
+                         hi = edge[static_cast<size_t>(2 * width * (k + 1))];
+            std::merge(src + lo, src + mid, src + mid, src + hi, dst + lo, less);
+        }
+        std::swap(src, dst);
+    }
+    if (src != v.data()) v.swap(other);
+}
 }  // namespace
 
 bool build_face_adjacency(const int32_t* cell_vert, int64_t n_cells, int64_t n_pts,
@@ -144,7 +177,7 @@ void unique_solid_faces(const double* tets, int64_t n_tets, std::vector<double>&
             if (bits(tets[3 * static_cast<size_t>(l) + k]) != bits(tets[3 * static_cast<size_t>(r) + k])) return false;
         return true;
     };
-    std::sort(order.begin(), order.end(), pt_less);
+    parallel_sort(order, pt_less);
     std::vector<int32_t> id_of(static_cast<size_t>(n_raw));
     points.clear();
     for (size_t i = 0; i < order.size(); ++i) {
@@ -166,7 +199,7 @@ void unique_solid_faces(const double* tets, int64_t n_tets, std::vector<double>&
             keys[static_cast<size_t>(4 * t + f)] = FaceKey{v[0], v[1], v[2], static_cast<uint32_t>(4 * t + f)};
         }
     }
-    std::sort(keys.begin(), keys.end(), [](const FaceKey& l, const FaceKey& r) {
+    parallel_sort(keys, [](const FaceKey& l, const FaceKey& r) {
         if (l.a != r.a) return l.a < r.a;
         if (l.b != r.b) return l.b < r.b;
         if (l.c != r.c) return l.c < r.c;
@@ -180,7 +213,7 @@ void unique_solid_faces(const double* tets, int64_t n_tets, std::vector<double>&
     uniq.reserve(keys.size());
     for (size_t i = 0; i < keys.size(); ++i)
         if (i == 0 || !key_eq(keys[i - 1], keys[i])) uniq.push_back(keys[i]);
-    std::sort(uniq.begin(), uniq.end(), [](const FaceKey& l, const FaceKey& r) {
+    parallel_sort(uniq, [](const FaceKey& l, const FaceKey& r) {
         const bool ls = (l.ref & 3u) == 3u, rs = (r.ref & 3u) == 3u;
         if (ls != rs) return !ls;
         return l.ref < r.ref;
