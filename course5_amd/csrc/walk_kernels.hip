@@ -283,11 +283,13 @@ __global__ __launch_bounds__(256) void entry_raster(GridView g, const double* __
 
     const double xmin = fmin(ax, fmin(bx, cx)), xmax = fmax(ax, fmax(bx, cx));
     const double ymin = fmin(ay, fmin(by, cy)), ymax = fmax(ay, fmax(by, cy));
-    // conservative pixel box (the tables are accumulated sums, so widen by one)
-    double fc0 = floor((xmin - im.x_min) / im.step_x) - 1.0;
-    double fc1 = ceil((xmax - im.x_min) / im.step_x) + 1.0;
-    double fr0 = floor((ymin - im.y_min) / im.step_y) - 1.0;
-    double fr1 = ceil((ymax - im.y_min) / im.step_y) + 1.0;
+    // conservative pixel box: floor / ceil already include a pixel on either side whose centre lies outside
+    // the face (the pixel coordinates are running sums, off from x_min + i * step by ~1e-13 of a pixel: far
+    // less than that margin needs)
+    double fc0 = floor((xmin - im.x_min) / im.step_x);
+    double fc1 = ceil((xmax - im.x_min) / im.step_x);
+    double fr0 = floor((ymin - im.y_min) / im.step_y);
+    double fr1 = ceil((ymax - im.y_min) / im.step_y);
     if (!(fc1 >= 0.0) || !(fr1 >= 0.0) || !(fc0 <= im.res_x - 1.0) || !(fr0 <= im.res_y - 1.0)) return;
     const int c0 = static_cast<int>(fmax(fc0, 0.0));
     const int c1 = static_cast<int>(fmin(fc1, im.res_x - 1.0));
