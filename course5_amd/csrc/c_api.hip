@@ -214,8 +214,11 @@ int ensure_image_buffers(c5_context* ctx) {
         C5_HIP(ctx, fs.first.ensure(static_cast<size_t>(padded) * sizeof(c5::Entry)));
         C5_HIP(ctx, fs.mask.ensure(static_cast<size_t>(padded) * sizeof(uint32_t)));
         C5_HIP(ctx, fs.row_cost.ensure(static_cast<size_t>(im.n_local_rows + 64) * sizeof(uint32_t)));
-        if (fs.entry_capacity < n_px / 8 + 1024) {  // overflow pool: re-entries only; grows on demand (C5_RETRY)
-            fs.entry_capacity = n_px / 8 + 1024;
+        // overflow pool: re-entries only; grows on demand (C5_RETRY).  It is cut into 64 shards and which
+        // entry of a pixel comes first is a race, so a shard's demand varies a little from frame to frame:
+        // sized generously
+        if (fs.entry_capacity < n_px / 4 + 8192) {
+            fs.entry_capacity = n_px / 4 + 8192;
             C5_HIP(ctx, fs.pool.ensure(static_cast<size_t>(fs.entry_capacity) * sizeof(c5::Entry)));
         }
     }
@@ -531,7 +534,7 @@ int finish_frame(c5_context* ctx) {
     }
     if (too_small) {
         st.entry_overflow += 1;
-        const int64_t want = max_entries + max_entries / 4 + 1024;
+        const int64_t want = max_entries + max_entries / 2 + 8192;
         for (int k = 0; k < (ctx->pipeline ? kFrameSlots : 1); ++k) {
             FrameSlot& o = ctx->slots[k];
             if (o.entry_capacity >= want) continue;

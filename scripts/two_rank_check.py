@@ -25,6 +25,8 @@ xyz, cells, alpha, q = mg.workload("c2")
 views = [mg.view_rotations(0.1 + 0.05 * k, 0.07 - 0.04 * k) for k in range(7)]
 
 ctx = capi.Context(0)
+if os.environ.get("C5_PIPELINE"):  # two frame slots inside the context as well
+    ctx.set_option("pipeline", int(os.environ["C5_PIPELINE"]))
 ctx.upload_grid(xyz, cells, alpha, q)
 ctx.set_image(res_x, res_y, mg.REFERENCE_BOUNDS)
 stream = torch.cuda.Stream(device=dev)
@@ -37,38 +39,41 @@ else:
     ctx.set_row_range(*blocks[rank])
 pipe = FramePipeline(res_x, res_y, rank, world, dev, depth=2, tile_rows=tile_rows, blocks=blocks, host_staging=True)
 got = []
+
+
+def any_rank_must_retry() -> bool:
+    """C5_RETRY (the entry pool grew) on any rank: every rank renders the frame(s) again."""
+    flag = torch.tensor([1 if ctx.synchronize() != capi.C5_OK else 0])
+    dist.all_reduce(flag)
+    return int(flag.item()) != 0
+
+
+def step(v):
+    def render(strip):
+        ctx.set_view(v)
+        ctx.render_device(strip.data_ptr())
+    pipe.step(render)
+
+
 with torch.cuda.stream(stream):
-    for attempt in range(2):  # the first pass may only size the entry pool (C5_RETRY)
-        got = []
-        for v in views:
-            def render(strip, v=v):
-                ctx.set_view(v)
-                ctx.render_device(strip.data_ptr())
-            pipe.step(render)
-            if len(pipe.pending) == 0 or True:
-                pass
-            # a frame is complete one step later (depth 2): collect it after the drain below
-        frame = pipe.drain()
-        if ctx.synchronize() == capi.C5_OK:
-            break
     # frame by frame, drained each time, so that every reassembled frame can be compared
     for v in views:
-        def render(strip, v=v):
-            ctx.set_view(v)
-            ctx.render_device(strip.data_ptr())
-        pipe.step(render)
-        frame = pipe.drain()
-        torch.cuda.synchronize()
+        for attempt in range(4):
+            step(v)
+            frame = pipe.drain()
+            torch.cuda.synchronize()
+            if not any_rank_must_retry():
+                break
         if rank == 0:
             got.append(frame.cpu().numpy().copy())
-    # and once more back to back (depth 2 in flight), comparing the last frame only
-    for v in views:
-        def render(strip, v=v):
-            ctx.set_view(v)
-            ctx.render_device(strip.data_ptr())
-        pipe.step(render)
-    last = pipe.drain()
-    torch.cuda.synchronize()
+    # and back to back (two gathers in flight), comparing the last frame only
+    for attempt in range(4):
+        for v in views:
+            step(v)
+        last = pipe.drain()
+        torch.cuda.synchronize()
+        if not any_rank_must_retry():
+            break
 ok = True
 if rank == 0:
     full = capi.Context(0)
