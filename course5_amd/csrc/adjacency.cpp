@@ -1,8 +1,11 @@
 #include "adjacency.hpp"
 
 #include <omp.h>
+#include <sched.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace c5 {
@@ -19,12 +22,44 @@ inline bool key_less(const FaceKey& l, const FaceKey& r) {
 }
 inline bool key_eq(const FaceKey& l, const FaceKey& r) { return l.a == r.a && l.b == r.b && l.c == r.c; }
 
+// Threads for the host-side loops: what OpenMP offers, but no more than the CPUs this process may
+// really use.  A container with a CPU quota still shows every core of the machine (256 here for a
+// quota of 16): a team of 256 burns the quota in a few milliseconds and the whole process — the
+// thread that enqueues the frames included — is then throttled for the rest of each period.
+int host_threads() {
+    static const int n = [] {
+        long cpus = omp_get_max_threads();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = std::min<long>(cpus, CPU_COUNT(&set));
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+            char quota[32] = {0};
+            long period = 0;
+            if (std::fscanf(f, "%31s %ld", quota, &period) == 2 && period > 0 && std::strcmp(quota, "max") != 0)
+                cpus = std::min(cpus, std::max(1L, std::atol(quota) / period));
+            std::fclose(f);
+        } else {
+            long quota = -1, period = 0;  // cgroup v1
+            if (FILE* q = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+                if (std::fscanf(q, "%ld", &quota) != 1) quota = -1;
+                std::fclose(q);
+            }
+            if (FILE* q = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (std::fscanf(q, "%ld", &period) != 1) period = 0;
+                std::fclose(q);
+            }
+            if (quota > 0 && period > 0) cpus = std::min(cpus, std::max(1L, quota / period));
+        }
+        return static_cast<int>(std::max(1L, std::min(cpus, 64L)));
+    }();
+    return n;
+}
+
 // Sort by (a, b, c) on all OpenMP threads: the keys are dealt into buckets by ranges of `a` (their
 // smallest point id, spread evenly over [0, n_ids)), the buckets are sorted independently, and their
 // concatenation is sorted.  (std::sort alone took 250 ms of the 290 ms of c5_upload_grid at 1M cells.)
 template <class Less>
 void sort_keys(std::vector<FaceKey>& keys, uint64_t n_ids, Less less) {
-    const int threads = omp_get_max_threads();
+    const int threads = host_threads();
     if (threads < 2 || keys.size() < (size_t{1} << 16) || n_ids == 0) {
         std::sort(keys.begin(), keys.end(), less);
         return;
@@ -77,7 +112,7 @@ template <class T, class Less>
 void parallel_sort(std::vector<T>& v, Less less) {
     const size_t n = v.size();
     int parts = 1;
-    while (parts * 2 <= omp_get_max_threads() && parts < 64) parts *= 2;
+    while (parts * 2 <= host_threads() && parts < 64) parts *= 2;
     if (parts < 2 || n < (size_t{1} << 16)) {
         std::sort(v.begin(), v.end(), less);
         return;
@@ -110,7 +145,7 @@ bool build_face_adjacency(const int32_t* cell_vert, int64_t n_cells, int64_t n_p
     static const int FV[4][3] = {{0, 1, 2}, {0, 1, 3}, {0, 2, 3}, {1, 2, 3}};
     std::vector<FaceKey> keys(static_cast<size_t>(4 * n_cells));
     bool bad_id = false;
-#pragma omp parallel for schedule(static) reduction(|| : bad_id)
+#pragma omp parallel for schedule(static) reduction(|| : bad_id) num_threads(host_threads())
     for (int64_t c = 0; c < n_cells; ++c) {
         const int32_t* v = cell_vert + 4 * c;
         for (int k = 0; k < 4; ++k)
