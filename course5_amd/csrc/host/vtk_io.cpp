@@ -277,7 +277,20 @@ namespace {
 
 // The writer's loops are short: more than a few dozen threads only add fork/join cost (and a box whose CPU
 // share is smaller than its core count runs the surplus threads one after the other).
-int writer_threads() { return std::min(omp_get_max_threads(), 32); }
+int writer_threads() {
+    static const int n = [] {
+        long cpus = std::min(omp_get_max_threads(), 32);
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // a container's CPU quota: "<quota|max> <period>"
+            char quota[32] = {0};
+            long period = 0;
+            if (std::fscanf(f, "%31s %ld", quota, &period) == 2 && period > 0 && std::strcmp(quota, "max") != 0)
+                cpus = std::min(cpus, std::max(1L, std::atol(quota) / period));
+            std::fclose(f);
+        }
+        return static_cast<int>(std::max(1L, cpus));
+    }();
+    return n;
+}
 
 // base64 of data[0, n) into out (4 * ceil(n / 3) characters); chunks of whole 3-byte groups in parallel
 void base64_into(const unsigned char* data, size_t n, char* out) {
