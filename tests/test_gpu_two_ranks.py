@@ -16,7 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("layout", ["cyclic", "blocks"])
 def test_two_ranks_reassemble_every_frame(layout):
     env = dict(os.environ, C5_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = {"cyclic": "29541", "blocks": "29542"}[layout]
+    import socket
+    with socket.socket() as sock:  # a port nobody holds right now
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", port,
                         os.path.join(ROOT, "scripts", "two_rank_check.py"), layout],
