@@ -40,7 +40,7 @@ class Stats(C.Structure):
                 ("walk_overflow", C.c_int32), ("entry_overflow", C.c_int32),
                 ("ms_transform", C.c_float), ("ms_records", C.c_float), ("ms_entries", C.c_float),
                 ("ms_solids", C.c_float), ("ms_walk", C.c_float), ("ms_total", C.c_float),
-                ("odd_pixels", C.c_int64)]
+                ("odd_pixels", C.c_int64), ("pool_entries", C.c_int64), ("pool_capacity", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -148,7 +148,7 @@ class Context:
 
     def set_stream(self, stream_ptr: int):
         """Run on a caller-owned HIP stream (e.g. torch.cuda.current_stream().cuda_stream); 0 = own."""
-        self._check(self.lib.c5_set_stream(self.handle, C.c_void_p(stream_ptr)))
+        return self._check(self.lib.c5_set_stream(self.handle, C.c_void_p(stream_ptr)), allow=(C5_RETRY,))
 
     # -- scene ---------------------------------------------------------------------------------
     def upload_grid(self, xyz, cells, alpha, q):
@@ -236,7 +236,7 @@ class Context:
 
     def view_points(self, n_pts: int) -> np.ndarray:
         out = np.empty((n_pts, 3), dtype=np.float64)
-        self._check(self.lib.c5_download_view_points(self.handle, _dp(out)))
+        self._check(self.lib.c5_download_view_points(self.handle, _dp(out)), allow=(C5_RETRY,))
         return out
 
 

@@ -214,9 +214,9 @@ int ensure_image_buffers(c5_context* ctx) {
         C5_HIP(ctx, fs.first.ensure(static_cast<size_t>(padded) * sizeof(c5::Entry)));
         C5_HIP(ctx, fs.mask.ensure(static_cast<size_t>(padded) * sizeof(uint32_t)));
         C5_HIP(ctx, fs.row_cost.ensure(static_cast<size_t>(im.n_local_rows + 64) * sizeof(uint32_t)));
-        // overflow pool: re-entries only; grows on demand (C5_RETRY).  It is cut into 64 shards and which
-        // entry of a pixel comes first is a race, so a shard's demand varies a little from frame to frame:
-        // sized generously
+        // overflow pool: second and further entries of a ray only.  A frame overflows iff its total demand
+        // exceeds the capacity (entry_raster); finish_frame keeps the capacity at twice the demand of the
+        // last frame it has seen, so only a jump of the demand between two looks can cost a C5_RETRY.
         if (fs.entry_capacity < n_px / 4 + 8192) {
             fs.entry_capacity = n_px / 4 + 8192;
             C5_HIP(ctx, fs.pool.ensure(static_cast<size_t>(fs.entry_capacity) * sizeof(c5::Entry)));
@@ -522,27 +522,47 @@ int finish_frame(c5_context* ctx) {
         for (int k = 0; k < 5; ++k) C5_HIP(ctx, hipEventElapsedTime(dst[k], fs.ev[k], fs.ev[k + 1]));
         C5_HIP(ctx, hipEventElapsedTime(&st.ms_total, fs.ev[0], fs.ev[5]));
     }
+    // overflow entries this frame needed: handed out (a shard hands out min(asked, its part)) + refused
+    int64_t handed = 0;
+    for (int k = 0; k < c5::kCounterShards; ++k) {
+        const int64_t part = (static_cast<int64_t>(k + 1) * fs.entry_capacity) / c5::kCounterShards -
+                             (static_cast<int64_t>(k) * fs.entry_capacity) / c5::kCounterShards;
+        handed += std::min<int64_t>(static_cast<int64_t>(fs.host_counters[k].pool_used), part);
+    }
+    st.pool_entries = handed + static_cast<int64_t>(hc.entry_overflow);
+    st.pool_capacity = fs.entry_capacity;
     // failures of ANY frame since the last look (several frames may have been in flight)
-    const int64_t max_entries = static_cast<int64_t>(ctx->host_sticky[0]);
+    const int64_t refused = static_cast<int64_t>(ctx->host_sticky[0]);  // entries that found no slot, all those frames
     const unsigned lost_rays = ctx->host_sticky[1];
-    const bool too_small = max_entries > fs.entry_capacity;
+    const bool too_small = refused > 0;
     if (too_small || lost_rays) {
         int rc = drain(ctx);
         if (rc) return rc;
         C5_HIP(ctx, hipMemset(ctx->sticky.ptr, 0, 2 * sizeof(unsigned)));
         ctx->host_sticky[0] = ctx->host_sticky[1] = 0;
     }
-    if (too_small) {
-        st.entry_overflow += 1;
-        const int64_t want = max_entries + max_entries / 2 + 8192;
+    // Keep the pool at twice the demand just seen (plus a margin): the demand is a smooth function of the
+    // view, so in a sweep the pool grows ahead of it, between frames, without a frame ever being lost.
+    int64_t want = 0;
+    if (too_small) want = 2 * (std::max(st.pool_entries, fs.entry_capacity) + refused) + 8192;
+    else if (2 * st.pool_entries + 4096 > fs.entry_capacity) want = 2 * st.pool_entries + 8192;
+    if (want > static_cast<int64_t>(16777214) * 64) want = static_cast<int64_t>(16777214) * 64;  // slot + 1 must fit 31 bits
+    if (want > fs.entry_capacity) {
+        int rc = drain(ctx);
+        if (rc) return rc;
         for (int k = 0; k < (ctx->pipeline ? kFrameSlots : 1); ++k) {
             FrameSlot& o = ctx->slots[k];
             if (o.entry_capacity >= want) continue;
             o.entry_capacity = want;
             C5_HIP(ctx, o.pool.ensure(static_cast<size_t>(want) * sizeof(c5::Entry)));
         }
-        return fail(ctx, C5_RETRY, "entry buffer grown to %lld records; render the frame(s) again",
-                    static_cast<long long>(want));
+    }
+    if (too_small) {
+        st.entry_overflow += 1;
+        return fail(ctx, C5_RETRY,
+                    "%lld boundary entries found no room in the overflow pool (now %lld records): every frame "
+                    "since the last c5_synchronize is incomplete, render again",
+                    static_cast<long long>(refused), static_cast<long long>(ctx->slots[0].entry_capacity));
     }
     if (lost_rays)
         return fail(ctx, C5_ERR_WALK, "%u rays exceeded the walk step bound (malformed grid?)", lost_rays);
@@ -676,7 +696,7 @@ int c5_set_stream(c5_context* ctx, void* hip_stream) {
     rc = wait_and_collect(ctx);
     ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
     ctx->using_caller_stream = hip_stream != nullptr;
-    return rc == C5_RETRY ? C5_OK : rc;
+    return rc;  // C5_RETRY included: the stream IS switched, but the frames before the switch must be rendered again
 }
 
 const char* c5_last_error(const c5_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
@@ -1055,8 +1075,8 @@ int c5_face_adjacency(const int32_t* cell_vert, int64_t n_cells, int64_t n_pts, 
 
 int c5_download_view_points(c5_context* ctx, double* xyz) {
     if (!ctx || !xyz) return fail(ctx, C5_ERR_INVALID, "null argument");
-    int rc = c5_synchronize(ctx);
-    if (rc && rc != C5_RETRY) return rc;
+    const int frame_rc = c5_synchronize(ctx);
+    if (frame_rc && frame_rc != C5_RETRY) return frame_rc;
     const size_t n = static_cast<size_t>(ctx->n_pts);
     std::vector<double> x(n), y(n), z(n);
     if (n) {
@@ -1069,7 +1089,7 @@ int c5_download_view_points(c5_context* ctx, double* xyz) {
         xyz[3 * i + 1] = y[i];
         xyz[3 * i + 2] = z[i];
     }
-    return C5_OK;
+    return frame_rc;  // the points are valid either way; C5_RETRY says the frame they belong to is not
 }
 
 }  // extern "C"

@@ -94,8 +94,8 @@ struct SolidTable {
 // Per-frame statistics.  The device holds kCounterShards copies, each on a 128-byte line of its own:
 // thousands of wavefronts adding to ONE address serialise at ~10 ns per atomic (three per covered
 // wavefront used to put a 0.7 ms floor under the C3 walk); spread over 64 lines they vanish.  The host
-// sums the shards (finish_frame).  Single-instance fields (pool_used, odd_pixels, the overflow flags)
-// live in shard 0.
+// sums the shards (finish_frame).  Single-instance fields (odd_pixels, the overflow words) live in
+// shard 0; pool_used is the allocation counter of shard k's part of the overflow pool (entry_raster).
 constexpr int kCounterShards = 64;
 struct alignas(128) FrameCounters {
     unsigned long long segments;
@@ -104,9 +104,9 @@ struct alignas(128) FrameCounters {
     unsigned long long solid_pixels;
     unsigned long long entries;
     unsigned int walk_overflow;
-    unsigned int entry_overflow;
+    unsigned int entry_overflow;  // shard 0: boundary entries that found no slot in the overflow pool this frame
     unsigned int odd_pixels;  // bin_sort_resolve: (pixel, cell) pairs with an odd number of covering faces
-    unsigned int pool_used;   // overflow entries handed out by entry_raster this frame
+    unsigned int pool_used;   // per shard: slots asked of this shard's part of the overflow pool (may exceed the part)
 };
 
 // global row -> local row of this rank, or -1

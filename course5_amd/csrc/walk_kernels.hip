@@ -379,30 +379,53 @@ __global__ __launch_bounds__(256) void entry_raster(GridView g, const double* __
             const bool more = in[k] && old[k] > 0;
             const unsigned long long more_mask = __builtin_amdgcn_ballot_w64(more);
             if (more_mask == 0ull) continue;
-            // (the pool is cut into kCounterShards equal parts, each with its counter on a line of its own:
-            // a non-convex grid makes tens of thousands of these allocations per frame)
-            const unsigned shard = static_cast<unsigned>(face_idx) % kCounterShards;
-            const unsigned shard_cap = static_cast<unsigned>(capacity / kCounterShards);
-            unsigned pool_base = 0;
-            if (lane == __builtin_ctzll(more_mask))
-                pool_base = atomicAdd(&counters[shard].pool_used, static_cast<unsigned>(__popcll(more_mask)));
-            pool_base = __builtin_amdgcn_readlane(pool_base, __builtin_ctzll(more_mask));
-            if (more) {
-                const unsigned local = pool_base + static_cast<unsigned>(__popcll(more_mask & ((1ull << lane) - 1ull)));
-                const unsigned slot = shard * shard_cap + local;
-                if (local < shard_cap) {
-                    Entry e;
-                    e.z = z[k];
-                    e.cell = static_cast<int32_t>(cell);
-                    e.next = atomicExch(&head[lp[k]].chain, static_cast<int32_t>(slot) + 1);
-                    pool[slot] = e;
-                } else {
-                    // pool too small: the host sees the demand in sticky[0], grows the pool and renders again
-                    // (the walk bounds-checks every hop, so this frame is merely wrong, never unsafe)
-                    // demand: as if every shard were as full as this one
-                    atomicOr(&counters->entry_overflow, 1u);
-                    atomicMax(sticky, (local + 1u) * kCounterShards);
+            // The pool is cut into kCounterShards parts, each with its counter on a line of its own (a
+            // non-convex grid makes tens of thousands of these allocations per frame; on ONE word they
+            // would serialise at ~10 ns each).  A request starts at its home shard and takes what that shard
+            // has left; what it still lacks it asks of the next shard, and so on round the ring: a slot is
+            // refused only when every shard is exhausted, i.e. a frame overflows if and only if its TOTAL
+            // demand (sum over the pixels of entries - 1, a property of grid, view and image alone)
+            // exceeds the capacity — never because of which faces hash to which shard or of the order
+            // the entries of a pixel arrive in.  (Round 1 gave every shard a fixed capacity / 64: one
+            // large re-entry face could overflow its shard with 63 others empty, and which entry of a
+            // pixel needs a slot at all is a race, so the same frame overflowed or not from run to run.)
+            const unsigned n_more = static_cast<unsigned>(__popcll(more_mask));
+            const unsigned my_rank = static_cast<unsigned>(__popcll(more_mask & ((1ull << lane) - 1ull)));
+            const int leader = __builtin_ctzll(more_mask);
+            unsigned shard = static_cast<unsigned>(face_idx) % kCounterShards;
+            unsigned taken = 0;  // wave-uniform: requests served so far
+            long long slot = -1;
+            for (int t = 0; t < kCounterShards && taken < n_more; ++t, shard = (shard + 1u) % kCounterShards) {
+                const unsigned lo = static_cast<unsigned>((static_cast<unsigned long long>(shard) * static_cast<unsigned long long>(capacity)) / kCounterShards);
+                const unsigned hi = static_cast<unsigned>((static_cast<unsigned long long>(shard + 1u) * static_cast<unsigned long long>(capacity)) / kCounterShards);
+                const unsigned cap_s = hi - lo;
+                const unsigned want = n_more - taken;
+                unsigned base = cap_s;
+                if (lane == leader) {
+                    // a shard known to be full is passed by without touching its counter (the counters only
+                    // grow within a frame, so a stale reading errs on the side of asking)
+                    unsigned* const used = &counters[shard].pool_used;
+                    if (__hip_atomic_load(used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cap_s) base = atomicAdd(used, want);
                 }
+                base = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(base), leader));
+                const unsigned avail = base < cap_s ? min(want, cap_s - base) : 0u;
+                if (more && my_rank >= taken && my_rank < taken + avail) slot = static_cast<long long>(lo) + base + (my_rank - taken);
+                taken += avail;
+            }
+            if (more && slot >= 0) {
+                Entry e;
+                e.z = z[k];
+                e.cell = static_cast<int32_t>(cell);
+                e.next = atomicExch(&head[lp[k]].chain, static_cast<int32_t>(slot) + 1);
+                pool[slot] = e;
+            }
+            if (taken < n_more && lane == leader) {
+                // pool exhausted: the frame is incomplete.  The host reads the number of entries that found
+                // no slot (this frame: counters[0].entry_overflow; any frame since it last looked: sticky[0]),
+                // grows the pool by at least that and reports C5_RETRY; the walk bounds-checks every hop,
+                // so such a frame is wrong but never unsafe.
+                atomicAdd(&counters->entry_overflow, n_more - taken);
+                atomicAdd(sticky, n_more - taken);
             }
         }
     }

@@ -23,10 +23,17 @@ from . import sharding
 
 class FramePipeline:
     def __init__(self, res_x: int, res_y: int, rank: int, world: int, device, depth: int = 2,
-                 tile_rows: int = 16, blocks=None, host_staging: bool = False):
+                 tile_rows: int = 16, blocks=None, host_staging: bool = False, check=None):
         """host_staging: rehearsal only (gloo backend, which cannot gather device tensors): strips
-        take a round trip through host memory around the gather."""
+        take a round trip through host memory around the gather.
+        check: callable returning the status of the frame just rendered (Context.synchronize: C5_OK or
+        C5_RETRY).  With it no strip is gathered before its render is known to be complete: a frame
+        reported C5_RETRY (an internal buffer was too small) is rendered again by this rank alone, before
+        its one gather of the step, so the ranks stay in step without exchanging flags.  The host then
+        waits for each render, but the gather of frame k still overlaps the render of frame k + 1."""
         self.host_staging = host_staging
+        self.check = check
+        self.retries = 0
         self.res_x, self.res_y, self.tile_rows = res_x, res_y, tile_rows
         self.rank, self.world, self.device = rank, world, device
         self.blocks = list(blocks) if blocks is not None else None
@@ -89,6 +96,14 @@ class FramePipeline:
             torch.cuda.current_stream().wait_event(self.assembled[s])
             self.assembled[s] = None
         render(self.strips[s])
+        if self.check is not None:
+            for _ in range(4):
+                if self.check() == 0:
+                    break
+                self.retries += 1
+                render(self.strips[s])
+            else:
+                raise RuntimeError("a frame kept being reported incomplete (C5_RETRY)")
         if self.world == 1:
             self.frame = self.strips[s]
             return

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define C5_ABI_VERSION 1
+#define C5_ABI_VERSION 2
 
 enum {
     C5_OK = 0,
@@ -41,8 +41,11 @@ enum {
     C5_ERR_MESH = 4,        /* c5_face_adjacency: a face is shared by more than two cells */
     C5_ERR_NO_DEVICE = 5,   /* no usable GPU */
     C5_ERR_WALK = 6,        /* a ray exceeded the step bound (malformed grid) */
-    C5_RETRY = 7            /* c5_synchronize: an internal buffer was too small and has been
-                               grown; the frame is incomplete, call c5_render_device again */
+    C5_RETRY = 7            /* an internal buffer was too small and has been grown: EVERY frame enqueued since
+                               the last call that waited for the stream is incomplete and must not be used;
+                               call c5_render_device again.  Reported by every call that waits for the stream
+                               (c5_synchronize, c5_get_stats, c5_set_stream, c5_get_row_costs,
+                               c5_download_view_points, c5_render_host_wait); c5_render retries by itself. */
 };
 
 #define C5_MAX_ROTATIONS 8
@@ -70,7 +73,7 @@ typedef struct c5_stats {
     int64_t boundary_faces;  /* static: faces with no neighbour */
     int64_t steps;           /* walk steps taken (>= segments) */
     int32_t walk_overflow;   /* rays that hit the step bound */
-    int32_t entry_overflow;  /* entry buffer had to grow (frame was re-rendered) */
+    int32_t entry_overflow;  /* the overflow pool was too small for this frame (C5_RETRY) */
     /* GPU time of the last frame per stage, milliseconds (HIP events on the context stream) */
     float ms_transform;      /* view transform                     (a2) */
     float ms_records;        /* per-cell walk records              (a1, a10) */
@@ -81,6 +84,9 @@ typedef struct c5_stats {
     int64_t odd_pixels;      /* bin_sort_resolve only: (pixel, cell) pairs covered by an odd number of the
                                 cell's faces, i.e. exactly degenerate alignment; the reference mis-pairs or
                                 aborts there (plane.cpp:39-41, line.cpp:40-47), here they are skipped */
+    int64_t pool_entries;    /* second and further entries of rays this frame needed room for (sum over the
+                                pixels of entries - 1): a property of grid, view and image alone */
+    int64_t pool_capacity;   /* room there was; the frame is complete iff pool_entries <= pool_capacity */
 } c5_stats;
 
 /* --- lifetime ----------------------------------------------------------------------------- */
@@ -94,7 +100,7 @@ const char* c5_last_error(const c5_context* ctx);
 /* Run the context's work on a caller-owned HIP stream (hipStream_t passed as void*), e.g. the
  * stream of the framework that owns the output buffer, so that ordering with the caller's own
  * kernels and collectives needs no host synchronisation.  NULL restores the context's own stream. */
-int c5_set_stream(c5_context* ctx, void* hip_stream);
+int c5_set_stream(c5_context* ctx, void* hip_stream);  /* waits for the old stream first: may return C5_RETRY */
 
 /* --- scene (persistent across frames) ------------------------------------------------------ */
 /* Volume grid: replaces object3d_base::read_vtk_file's per-cell copies (object3d_base.cpp:13-53)
@@ -160,7 +166,9 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  frame k is walked (set before c5_upload_grid / c5_set_image).  Default 0; measured
  *                  2 % faster on the C3 frame at the end of round 1 (a second set of per-view records).
  *   "entry_pool"   testing: size of the overflow pool of the per-pixel entry lists, in records (it holds
- *                  the second and further entries of a ray; it grows by itself through C5_RETRY).
+ *                  the second and further entries of a ray).  A frame is complete iff its total demand
+ *                  (c5_stats.pool_entries) fits; the library keeps the pool at twice the demand of the
+ *                  last frame it looked at and reports C5_RETRY for frames that did not fit.
  *   "lds_pad"      tuning: extra dynamic LDS per workgroup in bytes, to cap the resident wavefronts.
  *   "row_costs"    1: walk_composite also accumulates segments per image row (c5_get_row_costs).
  *   "stage_timing" / "walk_timing"  0/1: record HIP events per stage / around walk_composite. */

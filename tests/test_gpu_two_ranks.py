@@ -13,9 +13,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("layout", ["cyclic", "blocks"])
-def test_two_ranks_reassemble_every_frame(layout):
-    env = dict(os.environ, C5_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+@pytest.mark.parametrize("layout,extra", [("cyclic", {}), ("blocks", {}),
+                                          # the configuration of the round-1 wrong frame (two frame slots per context,
+                                          # blocks), started from a pool far too small: frames are re-rendered, never wrong
+                                          ("blocks", {"C5_PIPELINE": "1", "C5_ENTRY_POOL": "100"})],
+                         ids=["cyclic", "blocks", "blocks-two-slots-starved-pool"])
+def test_two_ranks_reassemble_every_frame(layout, extra):
+    env = dict(os.environ, C5_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
     import socket
     with socket.socket() as sock:  # a port nobody holds right now
         sock.bind(("127.0.0.1", 0))
@@ -25,3 +29,5 @@ def test_two_ranks_reassemble_every_frame(layout):
                         os.path.join(ROOT, "scripts", "two_rank_check.py"), layout],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "PASS" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    if extra:
+        assert "0 frame(s) rendered again" not in r.stdout, r.stdout[-2000:]  # the starved pool did cost re-renders
