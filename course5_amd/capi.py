@@ -26,7 +26,7 @@ EXPORTS = [
     "c5_local_rows", "c5_set_view", "c5_set_solid_view", "c5_set_alpha_limit", "c5_set_option",
     "c5_render", "c5_render_device", "c5_synchronize", "c5_get_stats", "c5_walk_kernel_ms",
     "c5_download_view_points", "c5_face_adjacency", "c5_set_stream",
-    "c5_set_row_range", "c5_get_row_costs",
+    "c5_set_row_range", "c5_get_row_costs", "c5_weld_points",
 ]
 
 
@@ -92,6 +92,7 @@ def load_library() -> C.CDLL:
     lib.c5_set_row_range.argtypes = [vp, C.c_int, C.c_int]
     lib.c5_get_row_costs.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int]
     lib.c5_face_adjacency.argtypes = [ip, C.c_int64, C.c_int64, ip, C.POINTER(C.c_int64)]
+    lib.c5_weld_points.argtypes = [dp, C.c_int64, ip, C.POINTER(C.c_int64)]
     for name in EXPORTS:
         if name not in ("c5_destroy", "c5_last_error"):
             getattr(lib, name).restype = C.c_int
@@ -251,6 +252,18 @@ def face_adjacency(cells, n_pts: int):
     if rc != C5_OK:
         raise C5Error(rc, lib.c5_last_error(None).decode())
     return adj, nb.value
+
+
+def weld_points(xyz):
+    """Host-only: (rep[n_pts], n_merged) via c5_weld_points."""
+    lib = load_library()
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+    rep = np.empty(xyz.shape[0], dtype=np.int32)
+    m = C.c_int64()
+    rc = lib.c5_weld_points(_dp(xyz), xyz.shape[0], rep.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(m))
+    if rc != C5_OK:
+        raise C5Error(rc, lib.c5_last_error(None).decode())
+    return rep, m.value
 
 
 def device_count() -> int:

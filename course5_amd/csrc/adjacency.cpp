@@ -140,6 +140,34 @@ void parallel_sort(std::vector<T>& v, Less less) {
 }
 }  // namespace
 
+int64_t weld_points(const double* xyz, int64_t n_pts, std::vector<int32_t>& rep) {
+    std::vector<uint32_t> order(static_cast<size_t>(n_pts));
+    for (int64_t i = 0; i < n_pts; ++i) order[static_cast<size_t>(i)] = static_cast<uint32_t>(i);
+    // by value (the coordinates are finite: c5_upload_grid checks), so -0.0 and 0.0 are one point; ties by id
+    auto pt_less = [&](uint32_t l, uint32_t r) {
+        for (int k = 0; k < 3; ++k) {
+            const double a = xyz[3 * static_cast<size_t>(l) + k], b = xyz[3 * static_cast<size_t>(r) + k];
+            if (a != b) return a < b;
+        }
+        return l < r;
+    };
+    auto pt_eq = [&](uint32_t l, uint32_t r) {
+        for (int k = 0; k < 3; ++k)
+            if (xyz[3 * static_cast<size_t>(l) + k] != xyz[3 * static_cast<size_t>(r) + k]) return false;
+        return true;
+    };
+    parallel_sort(order, pt_less);
+    rep.resize(static_cast<size_t>(n_pts));
+    int64_t merged = 0;
+    uint32_t head = 0;
+    for (size_t i = 0; i < order.size(); ++i) {
+        if (i == 0 || !pt_eq(order[i - 1], order[i])) head = order[i];  // smallest id of the run (ties sort by id)
+        else ++merged;
+        rep[order[i]] = static_cast<int32_t>(head);
+    }
+    return merged;
+}
+
 bool build_face_adjacency(const int32_t* cell_vert, int64_t n_cells, int64_t n_pts,
                           std::vector<int32_t>& adj, std::vector<uint32_t>& bfaces, std::string& err) {
     static const int FV[4][3] = {{0, 1, 2}, {0, 1, 3}, {0, 2, 3}, {1, 2, 3}};
@@ -161,6 +189,19 @@ bool build_face_adjacency(const int32_t* cell_vert, int64_t n_cells, int64_t n_p
     }
     if (bad_id) {
         err = "cell references a point id out of range";
+        return false;
+    }
+    // a cell that names a point twice (possible after welding coincident points) has no volume and two
+    // identical faces: it would become its own neighbour.  The reference bins and sorts such a cell like any
+    // other (its chords are zero); so does bin_sort_resolve, which takes grids a walk cannot.
+    bool repeated = false;
+#pragma omp parallel for schedule(static) reduction(|| : repeated) num_threads(host_threads())
+    for (int64_t c = 0; c < n_cells; ++c) {
+        const int32_t* v = cell_vert + 4 * c;
+        if (v[0] == v[1] || v[0] == v[2] || v[0] == v[3] || v[1] == v[2] || v[1] == v[3] || v[2] == v[3]) repeated = true;
+    }
+    if (repeated) {
+        err = "non-conforming grid: a cell names the same point twice";
         return false;
     }
     sort_keys(keys, static_cast<uint64_t>(n_pts), key_less);

@@ -15,6 +15,14 @@ namespace c5 {
 bool build_face_adjacency(const int32_t* cell_vert, int64_t n_cells, int64_t n_pts,
                           std::vector<int32_t>& adj, std::vector<uint32_t>& bfaces, std::string& err);
 
+// Point ids of coincident points made equal: rep[i] = smallest id whose coordinates equal those of
+// point i (rep[i] == i for a grid without duplicates).  The reference never looks at connectivity — it
+// copies four points per cell (object3d_base.cpp:37-42) — so a file whose cells carry private copies of
+// their points, or whose writer duplicated points along a seam, renders there like any other; here two
+// cells are neighbours only if they name the SAME ids, so the ids are welded by coordinate first.
+// Returns the number of points that were merged into another one.
+int64_t weld_points(const double* xyz, int64_t n_pts, std::vector<int32_t>& rep);
+
 // Solid tet soup [n][4][3] -> unique points (bitwise equal coordinates merged) and unique faces
 // (unordered point-id triples; 4 per tet before merging).  The centre-fan solids of the reference
 // (object3d_base.cpp:152-193) share every sliver face between two cells and every point between ~24,

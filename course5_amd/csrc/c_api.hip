@@ -516,6 +516,7 @@ int finish_frame(c5_context* ctx) {
     st.boundary_faces = ctx->n_bfaces;
     st.steps = static_cast<int64_t>(hc.steps);
     st.walk_overflow = static_cast<int32_t>(hc.walk_overflow);
+    st.entry_overflow = hc.entry_overflow > 0 ? 1 : 0;  // THIS frame; the sticky word below covers every frame in flight
     st.odd_pixels = static_cast<int64_t>(hc.odd_pixels);
     if (ctx->frame_timed) {
         float* dst[5] = {&st.ms_transform, &st.ms_records, &st.ms_entries, &st.ms_solids, &st.ms_walk};
@@ -558,7 +559,6 @@ int finish_frame(c5_context* ctx) {
         }
     }
     if (too_small) {
-        st.entry_overflow += 1;
         return fail(ctx, C5_RETRY,
                     "%lld boundary entries found no room in the overflow pool (now %lld records): every frame "
                     "since the last c5_synchronize is incomplete, render again",
@@ -714,6 +714,21 @@ int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int3
     int rc = bind_device(ctx);
     if (rc) return rc;
 
+    for (int64_t i = 0; i < 4 * n_cells; ++i)
+        if (cell_vert[i] < 0 || cell_vert[i] >= n_pts)
+            return fail(ctx, C5_ERR_INVALID, "cell %lld references a point id out of range", static_cast<long long>(i / 4));
+    // Coincident points are one point: the reference copies coordinates per cell (object3d_base.cpp:37-42)
+    // and never sees ids, so files with per-cell point copies or duplicated seam points must walk like any
+    // other grid (without this every face of such a file would be a boundary face).
+    std::vector<int32_t> welded;
+    {
+        std::vector<int32_t> rep;
+        if (c5::weld_points(xyz, n_pts, rep) > 0) {
+            welded.resize(static_cast<size_t>(4 * n_cells));
+            for (int64_t i = 0; i < 4 * n_cells; ++i) welded[static_cast<size_t>(i)] = rep[static_cast<size_t>(cell_vert[i])];
+            cell_vert = welded.data();
+        }
+    }
     std::vector<int32_t> adj;
     std::vector<uint32_t> bfaces;
     std::string err;
@@ -1070,6 +1085,17 @@ int c5_face_adjacency(const int32_t* cell_vert, int64_t n_cells, int64_t n_pts, 
         return fail(nullptr, err.find("range") != std::string::npos ? C5_ERR_INVALID : C5_ERR_MESH, "%s", err.c_str());
     if (n_cells > 0) std::memcpy(adj, a.data(), a.size() * sizeof(int32_t));
     if (n_boundary_faces) *n_boundary_faces = static_cast<int64_t>(b.size());
+    return C5_OK;
+}
+
+int c5_weld_points(const double* xyz, int64_t n_pts, int32_t* rep, int64_t* n_merged) {
+    if (n_pts < 0 || (n_pts > 0 && (!xyz || !rep))) return fail(nullptr, C5_ERR_INVALID, "bad weld arguments");
+    for (int64_t i = 0; i < 3 * n_pts; ++i)
+        if (!std::isfinite(xyz[i])) return fail(nullptr, C5_ERR_INVALID, "point %lld has a non-finite coordinate", static_cast<long long>(i / 3));
+    std::vector<int32_t> r;
+    const int64_t m = c5::weld_points(xyz, n_pts, r);
+    if (n_pts > 0) std::memcpy(rep, r.data(), r.size() * sizeof(int32_t));
+    if (n_merged) *n_merged = m;
     return C5_OK;
 }
 

@@ -136,6 +136,15 @@ def ball(n: int = 36, r: float = 0.45, centre=(1.0, 0.0, 0.0), jitter: float = 0
                     keep=lambda cen: np.linalg.norm(cen - c, axis=1) < r)
 
 
+def per_cell_point_copies(xyz: np.ndarray, cells: np.ndarray):
+    """The same grid as a soup: every cell gets four private points (what object3d_base::read_vtk_file
+    keeps of a file, object3d_base.cpp:37-42, and what some writers emit).  Returns (xyz', cells')."""
+    cells = np.asarray(cells)
+    soup_xyz = np.ascontiguousarray(np.asarray(xyz, dtype=np.float64)[cells.reshape(-1)])
+    soup_cells = np.arange(4 * len(cells), dtype=np.int32).reshape(-1, 4)
+    return soup_xyz, soup_cells
+
+
 def workload(name: str):
     """Named benchmark / test grids -> (xyz, cells, alpha, q)."""
     if name == "c1":

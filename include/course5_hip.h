@@ -106,8 +106,8 @@ int c5_set_stream(c5_context* ctx, void* hip_stream);  /* waits for the old stre
 /* Volume grid: replaces object3d_base::read_vtk_file's per-cell copies (object3d_base.cpp:13-53)
  * and the tetra AoS (tetra.hpp:12-46).  xyz[n_pts][3] raw (untransformed) points,
  * cell_vert[n_cells][4] point ids, alpha/q[n_cells] = AbsorpCoef / radEnLooseRate
- * (object3d_accretion_disk.cpp:4).  Builds face adjacency; n_cells must be < 2^28
- * (line.hpp:71-79).  A grid in which some face belongs to more than two cells cannot be walked:
+ * (object3d_accretion_disk.cpp:4).  Points with equal coordinates are welded (c5_weld_points), then the
+ * face adjacency is built; n_cells must be < 2^28 (line.hpp:71-79).  A grid in which some face belongs to more than two cells cannot be walked:
  * it is accepted and rendered with "algorithm" 1 (see c5_set_option). */
 int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int32_t* cell_vert,
                    int64_t n_cells, const double* alpha, const double* q);
@@ -193,6 +193,12 @@ int c5_walk_kernel_ms(c5_context* ctx, int reset, double* avg_ms, int64_t* launc
  * Returns C5_ERR_MESH when a face is shared by more than two cells. */
 int c5_face_adjacency(const int32_t* cell_vert, int64_t n_cells, int64_t n_pts, int32_t* adj,
                       int64_t* n_boundary_faces);
+
+/* Host-only helper (no GPU needed): the point welding c5_upload_grid applies before it builds the
+ * adjacency.  rep[i] = smallest point id whose coordinates equal point i's (rep[i] == i where nothing
+ * coincides).  The reference copies four points per cell and ignores ids (object3d_base.cpp:37-42), so
+ * coincident points are one point there by construction. */
+int c5_weld_points(const double* xyz, int64_t n_pts, int32_t* rep, int64_t* n_merged);
 
 /* Debug/inspection: transformed grid vertices of the last frame, xyz[n_pts][3]. */
 int c5_download_view_points(c5_context* ctx, double* xyz);

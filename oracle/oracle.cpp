@@ -146,6 +146,11 @@ struct Scene {
     std::vector<Tet> tets;
     std::vector<PixelState> px;  // [x][y] like plane.hpp:59-62 -> index x*res_y + y
     int threads = 1;
+    // Test-side economy, not reference behaviour: keep only rows j with j % row_stride == row_phase (their
+    // pixels are binned, resolved and written exactly as in a full render — pixels are independent,
+    // plane.cpp:161-169; the other rows stay zero).  Lets a 4800x3600 frame be checked on every k-th row.
+    int row_stride = 1, row_phase = 0;
+    bool keeps(size_t j) const { return row_stride <= 1 || static_cast<int>(j % static_cast<size_t>(row_stride)) == row_phase; }
     // line.hpp:84-85: per-pixel, per-thread pairing word; flag == (word != 0)
     std::vector<std::vector<uint32_t>> pend;  // [thread][pixel]
     std::vector<std::mutex> locks;            // striped stand-in for line.hpp:87
@@ -155,6 +160,7 @@ struct Scene {
 
     // line.cpp:29-67
     void add_hit(size_t i, size_t j, uint32_t id, int face, int tid) {
+        if (!keeps(j)) return;
         PixelState& P = px[pix(i, j)];
         if (P.marked) return;
         uint32_t& buf = pend[tid][pix(i, j)];
@@ -186,6 +192,7 @@ struct Scene {
                 const double colour = t.val[0];
                 hits += c5scan::scan_face(grid, t.p[fv[0]], t.p[fv[1]], t.p[fv[2]],
                                           [&](size_t i, size_t j) {
+                                              if (!keeps(j)) return;
                                               PixelState& P = px[pix(i, j)];  // line.cpp:246-249
                                               P.marked = true;
                                               P.mark = colour;
@@ -251,12 +258,34 @@ void c5o_pixel_coords(int res_x, int res_y, const double* bounds4, double* X, do
 //     [2] = solid-marked pixels; timing_ms[0..2] = grid ctor / binning / resolve;
 //   probe_ij/probe_out: optional per-pixel segment dump (n_probe pixels, up to probe_cap
 //     segments each as {tet, z_hi, dz}); probe_count[n_probe].
+int c5o_render_rows(const double* xyz, int64_t n_pts, const int32_t* cell_vert, int64_t n_cells,
+                    const double* alpha, const double* q, const double* rots, int n_rot,
+                    const double* solid_tets, const double* solid_colour, int64_t n_solid, int res_x,
+                    int res_y, const double* bounds4, double alpha_limit, int threads, float* out,
+                    int64_t* stats, double* timing_ms, const int32_t* probe_ij, int n_probe,
+                    int probe_cap, double* probe_out, int32_t* probe_count, char* err, int errlen,
+                    int row_stride, int row_phase);
+
 int c5o_render(const double* xyz, int64_t n_pts, const int32_t* cell_vert, int64_t n_cells,
                const double* alpha, const double* q, const double* rots, int n_rot,
                const double* solid_tets, const double* solid_colour, int64_t n_solid, int res_x,
                int res_y, const double* bounds4, double alpha_limit, int threads, float* out,
                int64_t* stats, double* timing_ms, const int32_t* probe_ij, int n_probe,
                int probe_cap, double* probe_out, int32_t* probe_count, char* err, int errlen) {
+    return c5o_render_rows(xyz, n_pts, cell_vert, n_cells, alpha, q, rots, n_rot, solid_tets, solid_colour, n_solid,
+                           res_x, res_y, bounds4, alpha_limit, threads, out, stats, timing_ms, probe_ij, n_probe,
+                           probe_cap, probe_out, probe_count, err, errlen, 1, 0);
+}
+
+// The same render restricted to the rows j with j % row_stride == row_phase (see Scene::keeps); the
+// statistics then count those rows only.
+int c5o_render_rows(const double* xyz, int64_t n_pts, const int32_t* cell_vert, int64_t n_cells,
+                    const double* alpha, const double* q, const double* rots, int n_rot,
+                    const double* solid_tets, const double* solid_colour, int64_t n_solid, int res_x,
+                    int res_y, const double* bounds4, double alpha_limit, int threads, float* out,
+                    int64_t* stats, double* timing_ms, const int32_t* probe_ij, int n_probe,
+                    int probe_cap, double* probe_out, int32_t* probe_count, char* err, int errlen,
+                    int row_stride, int row_phase) {
     try {
         if (res_x < 2 || res_y < 2) throw std::runtime_error("critical error. empty plane");
         if (n_cells + n_solid <= 0)
@@ -266,6 +295,8 @@ int c5o_render(const double* xyz, int64_t n_pts, const int32_t* cell_vert, int64
         if (threads < 1) threads = 1;
         Scene sc;
         sc.threads = threads;
+        sc.row_stride = row_stride < 1 ? 1 : row_stride;
+        sc.row_phase = row_phase;
 
         // object3d_base.cpp:13-53 — per-cell vertex copies; main.cpp:105-107 — view transform
         sc.tets.resize(static_cast<size_t>(n_cells + n_solid));
@@ -326,6 +357,7 @@ int c5o_render(const double* xyz, int64_t n_pts, const int32_t* cell_vert, int64
 #pragma omp for schedule(dynamic, 8) collapse(2)
             for (size_t i = 0; i < sc.grid.res_x; ++i) {
                 for (size_t j = 0; j < sc.grid.res_y; ++j) {
+                    if (!sc.keeps(j)) continue;
                     PixelState& P = sc.px[sc.pix(i, j)];
                     float* o = out + 2 * (j * sc.grid.res_x + i);
                     try {

@@ -79,8 +79,10 @@ class Oracle:
         return X, Y
 
     def render(self, xyz, cells, alpha, q, rots, res_x, res_y, bounds, alpha_limit=2.5,
-               solid_tets=None, solid_colour=None, threads=1, probes=None, probe_cap=512):
-        """Returns dict(image[Y,X,2] float32, segments, covered, marked, timing_ms, probes)."""
+               solid_tets=None, solid_colour=None, threads=1, probes=None, probe_cap=512, row_stride=1, row_phase=0):
+        """Returns dict(image[Y,X,2] float32, segments, covered, marked, timing_ms, probes).
+        row_stride > 1 ("port" only): render only the rows j with j % row_stride == row_phase (the others stay
+        zero, the counts cover the kept rows) — pixels are independent, so those rows equal a full render's."""
         xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
         cells = np.ascontiguousarray(cells, dtype=np.int32).reshape(-1, 4)
         alpha = np.ascontiguousarray(alpha, dtype=np.float64)
@@ -108,7 +110,7 @@ class Oracle:
                 n_probe = pij.shape[0]
                 pout = np.zeros((n_probe, probe_cap, 3))
                 pcnt = np.zeros(n_probe, dtype=np.int32)
-            fn = self.lib.c5o_render
+            fn = self.lib.c5o_render_rows
             fn.restype = C.c_int
             rc = fn(_ptr(xyz, _dp), C.c_int64(xyz.shape[0]), _ptr(cells, _ip), C.c_int64(cells.shape[0]),
                     _ptr(alpha, _dp), _ptr(q, _dp), _ptr(rots, _dp), C.c_int(rots.shape[0]),
@@ -116,11 +118,13 @@ class Oracle:
                     C.c_int(res_x), C.c_int(res_y), _ptr(bounds, _dp), C.c_double(alpha_limit),
                     C.c_int(threads), _ptr(out, _fp), _ptr(stats, _lp), _ptr(timing, _dp),
                     _ptr(pij, _ip), C.c_int(n_probe), C.c_int(probe_cap), _ptr(pout, _dp),
-                    _ptr(pcnt, _ip), err, C.c_int(512))
+                    _ptr(pcnt, _ip), err, C.c_int(512), C.c_int(row_stride), C.c_int(row_phase))
             res["timing_ms"] = timing
             if n_probe:
                 res["probes"] = [pout[k, :min(pcnt[k], probe_cap)].copy() for k in range(n_probe)]
         else:
+            if row_stride != 1:
+                raise ValueError("row_stride is a feature of the port oracle")
             fn = self.lib.c5r_render
             fn.restype = C.c_int
             rc = fn(_ptr(xyz, _dp), C.c_int64(xyz.shape[0]), _ptr(cells, _ip), C.c_int64(cells.shape[0]),

@@ -49,3 +49,25 @@ def gpu_ctx():
     ctx = capi.Context(0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(scope="session")
+def product_solids(tmp_path_factory):
+    """The Roche lobe and the accretor sphere as the `course` CLI generates them (csrc/host/scene.cpp,
+    restating object3d_base.cpp:83-196): raw soups [n][4][3], before any rotation.  Host-only."""
+    import subprocess
+    import numpy as np
+    from course5_amd import meshgen as mg
+    d = tmp_path_factory.mktemp("solids")
+    xs, cs = mg.cube8()
+    mg.write_vtk_ascii(str(d / "tiny.vtk"), xs, cs, *mg.scalars(len(cs)))
+    subprocess.run([os.path.join(ROOT, "course5_amd", "course"), "-f", str(d / "tiny.vtk"), "-d", str(d / "o.vti"),
+                    "--parse_only", "--dump_solids", str(d / "s.bin")], check=True, capture_output=True)
+    raw = open(d / "s.bin", "rb").read()
+    off, soups = 0, []
+    while off < len(raw):
+        n = int(np.frombuffer(raw, dtype=np.int64, count=1, offset=off)[0])
+        soups.append(np.frombuffer(raw, dtype=np.float64, count=12 * n, offset=off + 8).reshape(n, 4, 3).copy())
+        off += 8 + 96 * n
+    assert [len(s) for s in soups] == [130_560, 522_242]  # SURVEY.md section 2, rows 7 and 8
+    return soups

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(capi.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.c5_abi_version() == 1
+    assert lib.c5_abi_version() == 2
 
 
 def test_status_codes_match_header():
@@ -39,7 +39,7 @@ def test_status_codes_match_header():
 
 def test_struct_layouts():
     assert ctypes.sizeof(capi.Rotation) == 24
-    assert ctypes.sizeof(capi.Stats) == 6 * 8 + 2 * 4 + 6 * 4 + 8
+    assert ctypes.sizeof(capi.Stats) == 6 * 8 + 2 * 4 + 6 * 4 + 8 + 2 * 8
 
 
 def test_face_adjacency_helper_runs_without_a_gpu():
@@ -63,6 +63,38 @@ def test_non_conforming_grid_is_reported_by_the_adjacency_helper():
     with pytest.raises(capi.C5Error) as e:
         capi.face_adjacency(dup, len(xyz))
     assert e.value.code == capi.C5_ERR_MESH
+
+
+def test_point_welding_restores_the_adjacency_of_per_cell_point_copies():
+    """The reference copies four points per cell and never looks at ids (object3d_base.cpp:37-42): a file
+    whose cells carry private copies of their points renders there like any other.  c5_upload_grid welds
+    coincident points first (c5_weld_points), so such a soup gets the same adjacency as the indexed grid."""
+    xyz, cells = mg.kuhn_box(5, jitter=0.1)
+    soup_xyz, soup_cells = mg.per_cell_point_copies(xyz, cells)
+    assert len(soup_xyz) == 4 * len(cells)
+    rep, merged = capi.weld_points(soup_xyz)
+    assert merged == len(soup_xyz) - len(xyz)
+    assert (rep <= np.arange(len(rep))).all() and np.array_equal(soup_xyz[rep], soup_xyz)
+    # unwelded: every face is a boundary face; welded: the indexed grid's table
+    _, nb_raw = capi.face_adjacency(soup_cells, len(soup_xyz))
+    assert nb_raw == 4 * len(cells)
+    adj_w, nb_w = capi.face_adjacency(rep[soup_cells], len(soup_xyz))
+    adj, nb = capi.face_adjacency(cells, len(xyz))
+    assert nb_w == nb and np.array_equal(adj_w, adj)
+    # nothing coincides in an indexed grid: the identity; -0.0 and 0.0 are one coordinate
+    rep0, merged0 = capi.weld_points(xyz)
+    assert merged0 == 0 and np.array_equal(rep0, np.arange(len(xyz)))
+    rep1, merged1 = capi.weld_points(np.array([[0.0, 1.0, 2.0], [3.0, 1.0, 2.0], [-0.0, 1.0, 2.0]]))
+    assert merged1 == 1 and rep1.tolist() == [0, 1, 0]
+
+
+def test_a_cell_naming_a_point_twice_is_not_walkable():
+    xyz, cells = mg.cube8()
+    bad = cells.copy()
+    bad[3, 1] = bad[3, 0]
+    with pytest.raises(capi.C5Error) as e:
+        capi.face_adjacency(bad, len(xyz))
+    assert e.value.code == capi.C5_ERR_MESH and "twice" in e.value.message
 
 
 def test_create_without_gpu_fails_loudly():

@@ -1,0 +1,153 @@
+"""Edges of the input contract the reference handles in its own way:
+
+ * per-cell point copies / duplicated points: the reference copies four points per cell and never looks at
+   ids (object3d_base.cpp:37-42), so such files render like any other there; here the ids are welded by
+   coordinate before the adjacency is built, and the grid is walked as usual;
+ * geometry outside the image domain: plane::get_pixel_by_x/_y clamp the fractional pixel index
+   (plane.cpp:194-212), so a face (or the part of a face's row span) that lies wholly beyond a border is
+   smeared onto the border row / column (readme.md:46 "hit outside of domain").  The solid raster and
+   bin_sort_resolve ("algorithm" 1) reproduce that bit for bit; the walk deliberately renders only what is
+   geometrically inside the domain, so it agrees with the reference everywhere except on the outermost
+   rows / columns a smear can reach.
+"""
+import numpy as np
+import pytest
+
+from course5_amd import capi, meshgen as mg
+from parity import assert_images_match
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _reset(gpu_ctx):
+    for k in range(8):
+        gpu_ctx.set_solid(k, np.zeros((0, 12)))
+    for name, v in (("tile", 2), ("integration", 0), ("lds_stage", 1), ("algorithm", 0), ("xcd_mode", 2)):
+        gpu_ctx.set_option(name, v)
+    gpu_ctx.set_row_range(0, -1)
+    gpu_ctx.set_row_tiles(0, 0, 1)
+    yield
+    gpu_ctx.set_option("algorithm", 0)
+
+
+def _render(ctx, rots, rx, ry, bounds=mg.REFERENCE_BOUNDS):
+    ctx.set_image(rx, ry, bounds)
+    ctx.set_view(rots)
+    ctx.set_alpha_limit(2.5)
+    return ctx.render(), ctx.stats()
+
+
+def test_per_cell_point_copies_walk_like_the_indexed_grid(gpu_ctx, oracle_port):
+    """The C2 ball written the way object3d_base::read_vtk_file keeps it (four private points per cell):
+    same image bit for bit, same S, and it is still the WALK that renders it (steps > 0, one entry list)."""
+    xyz, cells, alpha, q = mg.workload("c2")
+    rots = mg.view_rotations(0.1, 0.07)
+    gpu_ctx.upload_grid(xyz, cells, alpha, q)
+    want, st0 = _render(gpu_ctx, rots, 400, 300)
+    soup_xyz, soup_cells = mg.per_cell_point_copies(xyz, cells)
+    gpu_ctx.upload_grid(soup_xyz, soup_cells, alpha, q)
+    got, st1 = _render(gpu_ctx, rots, 400, 300)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    for k in ("segments", "covered_pixels", "entries", "boundary_faces", "pool_entries"):
+        assert st1[k] == st0[k], k
+    assert st1["steps"] >= st1["segments"] > 0 and st1["boundary_faces"] < len(cells)
+    ref = oracle_port.render(soup_xyz, soup_cells, alpha, q, rots, 400, 300, mg.REFERENCE_BOUNDS, threads=8)
+    assert_images_match(got, ref["image"], "soup vs oracle")
+    assert st1["segments"] == ref["segments"]
+    # a seam of duplicated points (two halves of a box written separately): welded, no boundary inside
+    xa, ca = mg.kuhn_box(4, jitter=0.0)
+    left = ca[(xa[ca].mean(axis=1)[:, 0] < 1.0)]
+    right = ca[(xa[ca].mean(axis=1)[:, 0] >= 1.0)]
+    xyz2 = np.vstack([xa, xa])
+    cells2 = np.vstack([left, right + len(xa)]).astype(np.int32)
+    a2, q2 = mg.scalars(len(cells2), seed=3)
+    gpu_ctx.upload_grid(xyz2, cells2, a2, q2)
+    img2, st2 = _render(gpu_ctx, rots, 200, 150)
+    ref2 = oracle_port.render(xyz2, cells2, a2, q2, rots, 200, 150, mg.REFERENCE_BOUNDS, threads=8)
+    assert_images_match(img2, ref2["image"], "seam")
+    assert st2["segments"] == ref2["segments"] and st2["boundary_faces"] == 6 * 4 * 4 * 2
+    assert st2["entries"] == st2["covered_pixels"]  # convex once welded: one entry per covered ray
+
+
+def _oracle_or_none(oracle, *args, **kw):
+    """The reference aborts on an odd face-hit count per tet (plane.cpp:39-41) and a clamp smear can
+    produce one: such a scene has no reference answer."""
+    try:
+        return oracle.render(*args, **kw)
+    except RuntimeError as e:
+        if "odd number" in str(e) or "fatal data error" in str(e):
+            return None
+        raise
+
+
+def test_solids_across_the_domain_border_smear_like_the_reference(gpu_ctx, oracle_port):
+    """Solid boxes straddling and wholly beyond each border of the domain: the NaN / colour mask must equal
+    the reference's clamp smear (plane.cpp:194-212 via find_intersections_with_polygon, :96-97,126-127)."""
+    xyz, cells, alpha, q = mg.workload("g2")
+    rots = mg.view_rotations(0.1, 0.07)
+    gpu_ctx.upload_grid(xyz, cells, alpha, q)
+    b = mg.REFERENCE_BOUNDS  # {x_max, x_min, y_max, y_min} = 2.2, -0.2, 0.9, -0.9
+    compared = 0
+    for k, (lo, size) in enumerate([((2.05, -0.3, -0.1), 0.4),    # straddles x_max
+                                    ((-0.45, 0.2, 0.0), 0.4),     # straddles x_min
+                                    ((0.7, 0.75, -0.2), 0.35),    # straddles y_max
+                                    ((1.1, -1.1, 0.1), 0.35),     # straddles y_min
+                                    ((2.3, -0.5, 0.0), 0.3),      # wholly right of x_max: one smeared column
+                                    ((0.3, 1.0, 0.0), 0.25),      # wholly above y_max: smeared onto the last row
+                                    ((2.0, 0.7, 0.0), 0.5)]):     # the corner
+        sx, sc = mg.kuhn_box(2, lo=lo, size=size, jitter=0.07, seed=20 + k)
+        tets = sx[sc].reshape(-1, 12)
+        ref = _oracle_or_none(oracle_port, xyz, cells, alpha, q, rots, 320, 240, b, solid_tets=tets,
+                              solid_colour=np.full(len(tets), np.nan), threads=8)
+        if ref is None:
+            continue
+        gpu_ctx.set_solid(0, tets, float("nan"))
+        gpu_ctx.set_solid_view(0, np.zeros((0, 3)))
+        img, st = _render(gpu_ctx, rots, 320, 240)
+        assert st["solid_pixels"] == ref["marked"] > 0, (k, st["solid_pixels"], ref["marked"])
+        assert np.array_equal(np.isnan(img), np.isnan(ref["image"])), k
+        assert_images_match(img, ref["image"], f"solid box {k}")
+        compared += 1
+    assert compared >= 5
+
+
+def test_volume_grid_across_the_domain_border(gpu_ctx, oracle_port):
+    """A grid that sticks out of the domain on two sides.  bin_sort_resolve ("algorithm" 1) is the
+    reference's own binning including the clamp: equal to the oracle everywhere, smeared border pixels
+    included.  The walk renders only what lies inside the domain: equal to the oracle on every pixel that
+    no smear can reach (all but the outermost rows and columns), and on those it equals its own render of
+    the same scene in a domain widened by one pixel ring (i.e. the geometrically correct value)."""
+    rots = mg.view_rotations(0.1, 0.07)
+    rx, ry = 300, 220
+    b = np.array(mg.REFERENCE_BOUNDS, dtype=np.float64)
+    done = 0
+    for k, (lo, size, n) in enumerate([((1.7, 0.3, -0.4), 0.9, 4), ((-0.6, -1.2, -0.3), 0.8, 3), ((1.9, -0.4, -0.2), 0.6, 5)]):
+        xyz, cells = mg.kuhn_box(n, lo=lo, size=size, jitter=0.1, seed=40 + k)
+        alpha, q = mg.scalars(len(cells), seed=50 + k)
+        ref = _oracle_or_none(oracle_port, xyz, cells, alpha, q, rots, rx, ry, b, threads=8)
+        if ref is None:
+            continue
+        gpu_ctx.upload_grid(xyz, cells, alpha, q)
+        gpu_ctx.set_option("algorithm", 1)
+        exact, se = _render(gpu_ctx, rots, rx, ry, b)
+        gpu_ctx.set_option("algorithm", 0)
+        assert se["segments"] == ref["segments"] and se["covered_pixels"] == ref["covered"]
+        assert_images_match(exact, ref["image"], f"bin_sort_resolve, grid {k}")
+        walk, sw = _render(gpu_ctx, rots, rx, ry, b)
+        assert sw["walk_overflow"] == 0
+        assert_images_match(walk[1:-1, 1:-1], ref["image"][1:-1, 1:-1], f"walk, interior, grid {k}")
+        # the border ring of the walk = the same rays inside a domain one pixel larger on every side
+        sx, sy = (b[0] - b[1]) / (rx - 1), (b[2] - b[3]) / (ry - 1)
+        wide = np.array([b[0] + sx, b[1] - sx, b[2] + sy, b[3] - sy])
+        big, _ = _render(gpu_ctx, rots, rx + 2, ry + 2, wide)
+        ring = np.ones((ry, rx), dtype=bool)
+        ring[1:-1, 1:-1] = False
+        a, c = walk[ring].astype(np.float64), big[1:-1, 1:-1][ring].astype(np.float64)
+        # (pixel coordinates are running sums from a different start: equal to ~1e-13 of a pixel, so compare
+        # with the usual tolerance and allow the few silhouette pixels that flip)
+        bad = np.abs(a - c) > 1e-5 * np.maximum(np.abs(a), np.abs(c)) + 1e-6 * max(np.abs(c).max(), 1e-30)
+        assert bad.sum() <= 6, (k, int(bad.sum()))
+        assert sw["segments"] <= se["segments"]
+        done += 1
+    assert done >= 2

@@ -30,4 +30,6 @@ def test_two_ranks_reassemble_every_frame(layout, extra):
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "PASS" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
     if extra:
-        assert "0 frame(s) rendered again" not in r.stdout, r.stdout[-2000:]  # the starved pool did cost re-renders
+        import re
+        again = [int(m) for m in re.findall(r"rank \d+: (\d+) frame\(s\) rendered again", r.stdout)]
+        assert len(again) == 2 and min(again) > 0, r.stdout[-2000:]  # the starved pool did cost re-renders
