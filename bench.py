@@ -6,22 +6,30 @@
 
 A step = one frame through the whole hot path on data already resident in HBM: view transform ->
 per-cell records -> boundary entry raster -> walk_composite -> fp32 image in device memory
-(N > 1: each rank renders its cyclic row tiles, then one RCCL gather of the strips to rank 0 and
-the reassembly there).  Rank 0 prints ONE JSON line.
+(N > 1: each rank renders its rows, then one RCCL exchange per frame brings the strips to rank 0).
+Rank 0 prints ONE JSON line.
 
 value       whole-job Mrays/s = res_x * res_y * K / (max over ranks of the timed region) / 1e6
-roofline    dominant kernel walk_composite: algorithmic bytes per launch (SURVEY.md §8(d):
-            S * 144 B + P * 8 B) / its average duration, measured live with HIP events on the
-            stream the kernel runs on (c5_walk_kernel_ms)
-cpu_baseline  the CPU oracle (own restatement of the reference algorithm, OpenMP) timed on this
-            box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
-            It is the checker being timed as a baseline, never the product path.
+roofline    of the dominant kernel walk_composite, every fraction <= 1 by construction:
+              achieved / peak / frac   HBM-side bytes per launch (rocprofv3 PMC, profiles/<round>_roofline.json:
+                                       (2 x FETCH_SIZE + WRITE_SIZE) KiB, MI355X_MICROARCH.md HBM section) /
+                                       the kernel's average duration measured LIVE here with HIP events on the
+                                       stream it runs on, against the 8 TB/s HBM3E peak;
+              limiter                  what actually binds the kernel: the busiest unit by the same PMC passes
+                                       (VALU pipes, LDS, L2 requests, wavefront slots);
+              contract                 SURVEY.md section 8(d)'s algorithmic figure (S * 144 B + P * 8 B) / duration —
+                                       NOT a fraction of anything: the 160 MB of per-view records are re-read
+                                       from L2 / Infinity Cache ~130 times per ray, so it exceeds the HBM peak.
+cpu_baseline  the CPU oracle (own restatement of the reference algorithm, OpenMP) timed on this box's
+            host cores on the SAME workload at the SAME image size (rank 0, N = 1 only).  It is the checker
+            being timed as a baseline, never the product path.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import resource
 import sys
 import time
 
@@ -35,24 +43,30 @@ from course5_amd.pipeline import FramePipeline, gather_row_costs  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 HBM_ACHIEVABLE_GBS = 6290.0  # measured float4 copy, same table
+L2_PEAK_GBS = 34500.0        # aggregate L2, MI355X_MICROARCH.md "L2 (per XCD)"
 B_SEG_SURVEY = 144           # 16 cell->vertex + 16 adjacency + 96 vertices + 16 scalars
-B_SEG_RECORD = 160           # what walk_composite actually loads per step: 128 B CellRecord + 32 B CellOptics
+B_SEG_RECORD = 160           # what walk_composite actually reads per step: 128 B CellRecord + 32 B CellOptics
 B_PIX = 8                    # 2 x fp32 store per pixel
 TILE_ROWS = 16
+ROOFLINE_FILE = os.path.join(ROOT, "profiles", "roofline.json")  # written by scripts/summarize_profile.py
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--steps", type=int, default=300)
     p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--workload", default="c3", help="c3 (998 250 tets, default), c2, kuhnN")
     p.add_argument("--res", default="2400x1800", help="image size of the N = 1 workload")
     p.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                    help="N > 1: weak = per-GPU rays stay at --res (image grows by sqrt(N) per side; N = 4 is "
                         "BASELINE config 4, 4800x3600); strong = the same --res frame split over N GPUs")
+    p.add_argument("--mode", choices=["rows", "frames"], default="rows",
+                   help="N > 1: rows = every frame is split by rows over the ranks and exchanged (config 4); "
+                        "frames = frame k of a sweep is rendered whole by rank k mod N, no exchange (config 5)")
     p.add_argument("--tile", type=int, default=-1, help="wavefront tile shape override (0: 64x1, 1: 16x4, 2: 8x8)")
     p.add_argument("--lds-stage", type=int, default=-1, help="override: 1 = LDS-staged walk kernel, 0 = direct loads")
+    p.add_argument("--precision", type=int, default=-1, help="override of the \"precision\" option, if the library has it")
     p.add_argument("--pipeline", type=int, default=-1, help="override: overlap the next frame's setup with the walk (1) or not (0)")
     p.add_argument("--overlap-setup", type=int, default=-1, help="override: entry lists beside build_records (1) or serial (0)")
     p.add_argument("--own-stream", action="store_true", help="run on the context's own (high priority) stream")
@@ -61,12 +75,13 @@ def parse():
     p.add_argument("--solids", action="store_true", help="add the Roche lobe and the accretor sphere (generated by the course CLI)")
     p.add_argument("--backend", default="nccl", help="nccl (= RCCL, default); gloo only to rehearse N > 1 on one GPU")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample-res", default="1200x900")
-    p.add_argument("--pipeline-depth", type=int, default=2, help="N > 1: frames whose gather may be in flight")
+    p.add_argument("--no-host-image", action="store_true", help="skip the second figure: frames delivered to host memory")
+    p.add_argument("--no-steady", action="store_true", help="skip the clock-steadying frames after the W warm-up steps (profiling passes)")
+    p.add_argument("--cpu-sample-res", default="", help="image size of the CPU baseline (default: the benchmark's own)")
+    p.add_argument("--pipeline-depth", type=int, default=2, help="N > 1: frames whose exchange may be in flight")
     p.add_argument("--sharding", choices=["blocks", "cyclic"], default="cyclic",
                    help="N > 1: cyclic 16-row tiles (default: every rank renders AND sends 1/N of the image) or "
-                        "contiguous cost-balanced row blocks (faster to render at 8 ranks, but the edge ranks own "
-                        "large empty strips that still cross their xGMI link: DESIGN.md section 7)")
+                        "contiguous cost-balanced row blocks (received at their final offset, no reassembly)")
     p.add_argument("--row-base-cost", type=float, default=6.0,
                    help="blocks: fixed cost per pixel in segment units added when balancing (measured: an empty "
                         "pixel costs about six segments)")
@@ -85,31 +100,50 @@ def usable_cpus() -> int:
     return n
 
 
-def cpu_baseline(xyz, cells, alpha, q, rots, sample_res):
-    """Oracle ("port") on the host cores, bounded sample: same grid and view, reduced image."""
+def cpu_baseline(xyz, cells, alpha, q, rots, res):
+    """Oracle ("port") on the host cores: same grid, same view, same image size."""
     from oracle.pyoracle import Oracle
     cores = min(usable_cpus(), 32)  # 32 = MAX_NUMBER_OF_THREADS (config.hpp:39)
-    rx, ry = sample_res
+    rx, ry = res
+    rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
     r = Oracle("port").render(xyz, cells, alpha, q, rots, rx, ry, mg.REFERENCE_BOUNDS, threads=cores)
+    rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
     ctor, binning, resolve = (float(v) for v in r["timing_ms"])
     span = ctor + binning + resolve
     return {
         "value": rx * ry / span / 1e3, "unit": "Mrays/s", "cores": cores, "kind": "port",
-        "sample": f"same grid and view at {rx}x{ry} ({r['segments']} segments); span = pixel grid + binning + "
-                  f"resolve (the reference's own timed span, main.cpp:126-130) = {span:.0f} ms; "
-                  f"binning + resolve only = {binning + resolve:.0f} ms",
+        "sample": f"one whole frame of the same workload: same grid, view and image size {rx}x{ry} "
+                  f"({r['segments']} segments) on {cores} OpenMP threads; span = pixel grid + binning + resolve "
+                  f"(the reference's own timed span, main.cpp:126-130) = {span:.0f} ms; binning + resolve only = "
+                  f"{binning + resolve:.0f} ms; peak RSS of the process {rss1 / 1e6:.2f} GB (before: {rss0 / 1e6:.2f})",
         "value_bin_resolve_only": rx * ry / (binning + resolve) / 1e3,
     }, r["segments"]
 
 
-def load_traffic():
-    """HBM bytes per walk_composite launch from the committed rocprofv3 PMC summary, if any."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+def load_roofline_counters():
+    """Per-launch PMC figures of walk_composite from the committed rocprofv3 summary, if any."""
     try:
-        with open(path) as f:
+        with open(ROOFLINE_FILE) as f:
             return json.load(f)
     except Exception:
         return None
+
+
+def product_solids():
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        xs, cs = mg.cube8()
+        mg.write_vtk_ascii(f"{d}/tiny.vtk", xs, cs, *mg.scalars(len(cs)))
+        subprocess.run([os.path.join(ROOT, "course5_amd", "course"), "-f", f"{d}/tiny.vtk", "-d", f"{d}/o.vti",
+                        "--parse_only", "--dump_solids", f"{d}/s.bin"], check=True, capture_output=True)
+        raw = open(f"{d}/s.bin", "rb").read()
+    off, soups = 0, []
+    while off < len(raw):
+        n = int(np.frombuffer(raw, dtype=np.int64, count=1, offset=off)[0])
+        soups.append(np.frombuffer(raw, dtype=np.float64, count=12 * n, offset=off + 8).reshape(n, 12))
+        off += 8 + 96 * n
+    return soups
 
 
 def main():
@@ -132,6 +166,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rdev = dev if args.backend == "nccl" else torch.device("cpu")  # where small reductions live
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
@@ -141,7 +176,8 @@ def main():
 
     res_x, res_y = (int(v) for v in args.res.lower().split("x"))
     base_res = (res_x, res_y)
-    if world > 1 and args.scaling == "weak":
+    frame_parallel = world > 1 and args.mode == "frames"
+    if world > 1 and args.scaling == "weak" and not frame_parallel:
         res_x, res_y = int(round(res_x * world ** 0.5)), int(round(res_y * world ** 0.5))
     xyz, cells, alpha, q = mg.workload(args.workload)
     rots = mg.view_rotations(**mg.BENCH_VIEW)
@@ -159,37 +195,29 @@ def main():
         ctx.set_option("tile", args.tile)
     if args.lds_stage >= 0:
         ctx.set_option("lds_stage", args.lds_stage)
+    if args.precision >= 0:
+        ctx.set_option("precision", args.precision)
     if args.overlap_setup >= 0:
         ctx.set_option("overlap_setup", args.overlap_setup)
     if not args.own_stream:
         ctx.set_stream(stream.cuda_stream)
 
     if args.solids:
-        import subprocess
-        import tempfile
-        with tempfile.TemporaryDirectory() as d:
-            xs, cs = mg.cube8()
-            mg.write_vtk_ascii(f"{d}/tiny.vtk", xs, cs, *mg.scalars(len(cs)))
-            subprocess.run([os.path.join(ROOT, "course5_amd", "course"), "-f", f"{d}/tiny.vtk", "-d", f"{d}/o.vti",
-                            "--parse_only", "--dump_solids", f"{d}/s.bin"], check=True, capture_output=True)
-            raw = open(f"{d}/s.bin", "rb").read()
-        off, soups = 0, []
-        while off < len(raw):
-            n = int(np.frombuffer(raw, dtype=np.int64, count=1, offset=off)[0])
-            soups.append(np.frombuffer(raw, dtype=np.float64, count=12 * n, offset=off + 8).reshape(n, 12))
-            off += 8 + 96 * n
+        soups = product_solids()
         ctx.set_solid(0, soups[0])
         ctx.set_solid(1, soups[1])
         ctx.set_solid_view(1, np.zeros((0, 3)))  # the sphere is never rotated (main.cpp:116)
         ctx.set_solid_view(0, np.vstack([[1.0, 0.0, 1.0], rots]))
 
-    sweep_k = [0]
+    # frame k of a sweep: in frame-parallel mode rank r renders frames r, r + N, r + 2N, ...
+    sweep_k = [rank if frame_parallel else 0]
+    sweep_stride = world if frame_parallel else 1
 
     def advance_view():
         if args.sweep == "none":
             return
-        sweep_k[0] += 1
         ang = sweep_k[0] / 180.0
+        sweep_k[0] += sweep_stride
         if args.sweep == "Y":
             r = mg.view_rotations(mg.BENCH_VIEW["angle_around_x"], mg.BENCH_VIEW["angle_around_y"] + ang)
             ctx.set_view(r)
@@ -203,39 +231,71 @@ def main():
         ctx.render_device(strip.data_ptr())
 
     blocks = None
+    sharded = world > 1 and not frame_parallel
     with torch.cuda.stream(stream):
-        if world > 1 and args.sharding == "cyclic":
+        if sharded and args.sharding == "cyclic":
             ctx.set_row_tiles(TILE_ROWS, rank, world)
-        elif world > 1:
+        elif sharded:
             # one probe frame on equal blocks measures segments per row; every rank then derives the
             # same cost-balanced contiguous blocks (pixels are independent: plane.cpp:161-169)
             eq = sharding.equal_blocks(res_y, world)
             ctx.set_row_range(*eq[rank])
             ctx.set_option("row_costs", 1)
             probe = torch.zeros((eq[rank][1], res_x, 2), dtype=torch.float32, device=dev)
-            render(probe)
-            while ctx.synchronize() == capi.C5_RETRY:
+            for _ in range(4):
                 render(probe)
-            costs = gather_row_costs(ctx.row_costs(), eq, rank, world, dev if args.backend == "nccl" else torch.device("cpu"))
+                if ctx.synchronize() == capi.C5_OK:
+                    break
+            costs = gather_row_costs(ctx.row_costs(), eq, rank, world, rdev)
             blocks = sharding.balanced_blocks(costs, world, base_cost=res_x * args.row_base_cost)
             ctx.set_option("row_costs", 0)
             ctx.set_row_range(*blocks[rank])
             del probe
     n_local = ctx.local_rows
-    pipe = FramePipeline(res_x, res_y, rank, world, dev, depth=args.pipeline_depth, tile_rows=TILE_ROWS, blocks=blocks,
-                         host_staging=args.backend != "nccl")
+    # N > 1, rows: no strip is exchanged before its render is known to be complete (FramePipeline.check): a
+    # C5_RETRY is settled by the rank it happened on, before its one exchange of the step, so the ranks
+    # never disagree on the number of collectives.  N = 1 / frames: frames run back to back and the status
+    # is read once after the timed region (a retry there re-times the region and is reported).
+    pipe = FramePipeline(res_x, res_y, rank, world if sharded else 1, dev, depth=args.pipeline_depth, tile_rows=TILE_ROWS,
+                         blocks=blocks, host_staging=args.backend != "nccl", check=ctx.synchronize if sharded else None)
+    retries = 0
+
+    def settle():
+        """After a burst without per-frame checks: wait, and render again while the library says C5_RETRY."""
+        nonlocal retries
+        pipe.drain()
+        for _ in range(4):
+            if ctx.synchronize() == capi.C5_OK:
+                return
+            retries += 1
+            pipe.step(render)
+            pipe.drain()
+        raise SystemExit("frames kept being reported incomplete (C5_RETRY)")
 
     with torch.cuda.stream(stream):
-        # warm-up (also lets the entry buffer reach its size: C5_RETRY means "render again")
         for k in range(max(args.warmup, 1)):
             pipe.step(render)
-            if k < 2:
-                pipe.drain()
-                while ctx.synchronize() == capi.C5_RETRY:
+            if k < 2 and not sharded:
+                settle()  # the first frames size the internal buffers
+        settle()
+        # clock-steadying frames (untimed, not counted in W): a 20-frame warm-up is 15 ms, far too short for
+        # the clocks to settle (round 1: 0.670 ms per walk in the driver's short run vs 0.606 sustained).
+        # Batches of 50 frames until the walk time of a batch is within 1 % of the one before (at most 2 s).
+        steady = []
+        if not args.no_steady:
+            ctx.walk_kernel_ms(reset=True)
+            t_lim = time.perf_counter() + 2.0
+            while time.perf_counter() < t_lim:
+                for _ in range(50):
                     pipe.step(render)
-                    pipe.drain()
-        pipe.drain()
-        ctx.synchronize()
+                pipe.drain()
+                ms, _ = ctx.walk_kernel_ms(reset=True)
+                steady.append(ms)
+                if len(steady) >= 2 and abs(steady[-1] - steady[-2]) <= 0.01 * steady[-1]:
+                    break
+            settle()
+        if args.sweep != "none":
+            sweep_k[0] = rank if frame_parallel else 0
         stats = ctx.stats()
         ctx.walk_kernel_ms(reset=True)
 
@@ -251,78 +311,109 @@ def main():
             if world > 1:
                 dist.barrier()
             elapsed = time.perf_counter() - t0
-            # a frame that made an internal buffer grow (C5_RETRY) invalidates the timed region on every rank:
-            # time the K steps again (the buffer has its size now)
-            redo = torch.tensor([1 if ctx.synchronize() != capi.C5_OK else 0], dtype=torch.int64,
-                                device=dev if args.backend == "nccl" else torch.device("cpu"))
+            # A frame that made an internal buffer grow (C5_RETRY) inside a region without per-frame checks
+            # invalidates that region on every rank: time the K steps again.  A hard error is an error.
+            rc = ctx.synchronize()
+            redo = torch.tensor([1 if rc == capi.C5_RETRY else 0], dtype=torch.int64, device=rdev)
             if world > 1:
                 dist.all_reduce(redo)
             walk_ms, walk_launches = ctx.walk_kernel_ms(reset=True)
             if int(redo.item()) == 0:
                 break
+            retries += 1
+            if args.sweep != "none":
+                sweep_k[0] = rank if frame_parallel else 0
         else:
             raise SystemExit("frames kept being re-rendered inside the timed region")
+    retries += pipe.retries
 
-    rdev = dev if args.backend == "nccl" else torch.device("cpu")
+    host_image = None
+    if world == 1 and not args.no_host_image and hasattr(ctx, "render_host_async"):
+        host_image = ctx.bench_host_frames(min(args.steps, 100))
+
     el = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
-    seg = torch.tensor([stats["segments"], n_local * res_x], dtype=torch.int64, device=rdev)
+    seg = torch.tensor([stats["segments"], n_local * res_x, retries], dtype=torch.int64, device=rdev)
     wk = torch.tensor([walk_ms], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(seg, op=dist.ReduceOp.SUM)
         dist.all_reduce(wk, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    S_total, P_total = int(seg[0].item()), int(seg[1].item())
+    S_total, P_total, retries_total = (int(v) for v in seg.tolist())
 
     if rank == 0:
+        frames = args.steps * (world if frame_parallel else 1)
         rays = res_x * res_y
         ms_per_step = elapsed * 1e3 / args.steps
-        value = rays * args.steps / elapsed / 1e6
-        # roofline of walk_composite on rank 0 (its own rows): algorithmic bytes per launch / duration
+        value = rays * frames / elapsed / 1e6
+        # roofline of walk_composite on rank 0 (its own rows)
         S_rank, P_rank = stats["segments"], n_local * res_x
         alg_bytes = S_rank * B_SEG_SURVEY + P_rank * B_PIX
-        achieved = alg_bytes / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else 0.0
-        traffic = load_traffic()
+        secs = walk_ms * 1e-3
+        pmc = load_roofline_counters() if (world == 1 and args.workload == "c3" and base_res == (2400, 1800) and
+                                            not args.solids and args.sweep == "none") else None
+        hbm_bytes = pmc.get("hbm_bytes_per_launch") if pmc else None
+        achieved = hbm_bytes / secs / 1e9 if (hbm_bytes and secs > 0) else None
         roofline = {
-            "bound": "hbm", "kernel": "walk_composite", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
-            "traffic_source": (traffic or {}).get("source"),
+            "bound": "hbm", "kernel": "walk_composite",
+            "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+            "traffic": hbm_bytes,
+            "traffic_source": (pmc or {}).get("source"),
             "kernel_ms": round(walk_ms, 4), "launches": walk_launches,
-            "algorithmic_bytes_per_launch": alg_bytes,
-            "bytes_per_segment": B_SEG_SURVEY, "bytes_per_pixel": B_PIX,
-            "segments_per_launch": S_rank, "pixels_per_launch": P_rank,
-            "record_bytes_per_segment": B_SEG_RECORD,
-            "achieved_record_accounting": round((S_rank * B_SEG_RECORD + P_rank * B_PIX) / (walk_ms * 1e-3) / 1e9, 1)
-            if walk_ms > 0 else 0.0,
-            "frac_of_achievable_6290": round(achieved / HBM_ACHIEVABLE_GBS, 4),
-            "note": "algorithmic bytes exceed HBM traffic: the per-view records (160 MB) are served by L2 / "
-                    "Infinity Cache, so frac > 1 is possible; see traffic for the measured HBM bytes",
+            "kernel_ms_rocprofv3": (pmc or {}).get("kernel_ms_rocprofv3"),
+            "limiter": (pmc or {}).get("limiter"),
+            "units": (pmc or {}).get("units"),
+            "contract": {
+                "what": "SURVEY.md section 8(d): algorithmic bytes (S x 144 B + P x 8 B) / kernel time. Not a fraction "
+                        "of a hardware limit: the per-view records (160 MB) are re-read from L2 / Infinity Cache, "
+                        "HBM sees `traffic` bytes per launch",
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "achieved_gbs": round(alg_bytes / secs / 1e9, 1) if secs > 0 else None,
+                "x_hbm_peak": round(alg_bytes / secs / 1e9 / HBM_PEAK_GBS, 3) if secs > 0 else None,
+                "bytes_per_segment": B_SEG_SURVEY, "bytes_per_pixel": B_PIX,
+                "segments_per_launch": S_rank, "pixels_per_launch": P_rank,
+                "record_bytes_per_segment": B_SEG_RECORD,
+            },
         }
+        if world == 1:
+            metric = "Mrays/sec at 2400x1800 on 1M-tet grid"
+        elif frame_parallel:
+            metric = (f"Mrays/sec, sweep of whole {res_x}x{res_y} frames dealt to {world} GPUs (frame k -> GPU k mod N, "
+                      f"no exchange): STRONG scaling of the sweep")
+        elif args.scaling == "weak":
+            metric = (f"Mrays/sec, WEAK scaling: {base_res[0]}x{base_res[1]} rays per GPU, one {res_x}x{res_y} image "
+                      f"split by rows over {world} GPUs (an N-fold value here is not north_star's fixed-frame speed-up)")
+        else:
+            metric = f"Mrays/sec, STRONG scaling: one {res_x}x{res_y} frame split by rows over {world} GPUs"
         out = {
-            "metric": "Mrays/sec at 2400x1800 on 1M-tet grid", "value": round(value, 2), "unit": "Mrays/s",
+            "metric": metric, "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
+            "higher_is_better": True,
+            "scaling": "weak" if world == 1 else ("strong" if frame_parallel else args.scaling),
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic", "retries": retries_total,
+            "steadying": {"batches_of_50_frames": len(steady), "walk_ms_per_batch": [round(v, 4) for v in steady]},
             "config": {"workload": f"{args.workload}: Kuhn box 55^3 = {cells.shape[0]} tets, {xyz.shape[0]} points, "
                                    f"jitter 0.1h, alpha~U[0,4) Q~U[0,1) seed 1234; {res_x}x{res_y}; view -X 0.1 -Y 0.07; "
-                                   f"alpha_limit 2.5; no solids" if args.workload == "c3" else
+                                   f"alpha_limit 2.5; {'Roche lobe + sphere' if args.solids else 'no solids'}" if args.workload == "c3" else
                                    f"{args.workload}: {cells.shape[0]} tets; {res_x}x{res_y}",
                        "parallelism": "single GPU" if world == 1 else
-                                      (f"row tiles of {TILE_ROWS} rows dealt cyclically to {world} ranks" if blocks is None else
-                                       f"{world} contiguous row blocks balanced by measured segments per row "
-                                       f"(rows per rank {[n for _, n in blocks]})") +
-                                      ", grid replicated, one RCCL gather per frame to rank 0",
-                       "segments_per_frame": S_total, "pixels_per_frame": P_total,
+                                      (f"whole frames dealt round-robin to {world} ranks, grid replicated, no exchange" if frame_parallel else
+                                       (f"row tiles of {TILE_ROWS} rows dealt cyclically to {world} ranks" if blocks is None else
+                                        f"{world} contiguous row blocks balanced by measured segments per row "
+                                        f"(rows per rank {[n for _, n in blocks]})") +
+                                       ", grid replicated, one RCCL exchange per frame to rank 0"),
+                       "segments_per_frame": S_total if not frame_parallel else stats["segments"],
+                       "pixels_per_frame": P_total if not frame_parallel else res_x * res_y,
                        "sweep": args.sweep, "solids": bool(args.solids),
                        "rays_per_gpu": P_total // world,
-                       "scaling_note": None if world == 1 else
-                       (f"weak: {base_res[0]}x{base_res[1]} rays per GPU, image {res_x}x{res_y}" if args.scaling == "weak"
-                        else f"strong: one {res_x}x{res_y} frame split over {world} GPUs")},
+                       "frames_timed": frames},
             "roofline": roofline,
         }
+        if host_image is not None:
+            out["value_host_image"] = host_image
         if world == 1 and not args.no_cpu_baseline:
-            sres = tuple(int(v) for v in args.cpu_sample_res.lower().split("x"))
+            sres = tuple(int(v) for v in args.cpu_sample_res.lower().split("x")) if args.cpu_sample_res else (res_x, res_y)
             out["cpu_baseline"], _ = cpu_baseline(xyz, cells, alpha, q, rots, sres)
         print(json.dumps(out), flush=True)
 

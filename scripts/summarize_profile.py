@@ -4,7 +4,8 @@
 
 Reads  gpurun_out/prof_kt/kt_kernel_stats.csv            (--kernel-trace --stats)
        gpurun_out/pmc_<COUNTER>/pmc_counter_collection.csv (one --pmc pass per counter group)
-Writes profiles/<round>_kernel_stats.csv, profiles/<round>_pmc.md, profiles/traffic.json.
+Writes profiles/<round>_kernel_stats.csv, profiles/<round>_pmc.md, profiles/traffic.json and
+profiles/roofline.json (what bench.py reads: per-launch HBM bytes and how busy each unit is).
 
 HBM traffic follows MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE come from separate passes,
 are in KiB, and on gfx950 FETCH_SIZE counts 64 B per 128-B request, so reads are doubled.
@@ -32,6 +33,70 @@ def per_kernel_counter(path):
     return acc
 
 
+def kernel_avg_ms(tag, walk):
+    """Average duration of the walk kernel in the kernel-trace summary (the default bench command)."""
+    path = os.path.join(PROF, f"{tag}_kernel_stats.csv")
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if "walk_composite" in row.get("Name", ""):
+                return float(row["AverageNs"]) / 1e6, int(row["Calls"])
+    return None, 0
+
+
+def write_roofline(tag, walk, c):
+    """profiles/roofline.json: every figure per launch of the walk kernel; fractions are of what the
+    hardware could do in the launch's own duration (GRBM_GUI_ACTIVE / 8 = shader cycles of the launch)."""
+    get = lambda k: c[k][0] if k in c else None  # noqa: E731
+    cycles = get("GRBM_GUI_ACTIVE") / 8.0 if get("GRBM_GUI_ACTIVE") else None  # summed over the 8 XCDs
+    n_simd, n_cu = 1024, 256
+    units = {}
+    if cycles:
+        if get("SQ_ACTIVE_INST_VALU"):  # quad-cycles a SIMD's vector pipe was executing, summed over SIMDs
+            units["valu"] = {"frac": 4.0 * get("SQ_ACTIVE_INST_VALU") / (cycles * n_simd),
+                             "what": "4 x SQ_ACTIVE_INST_VALU / (cycles x 1024 SIMDs): share of the launch the vector pipes were executing"}
+        if get("SQ_LDS_IDX_ACTIVE"):
+            units["lds"] = {"frac": get("SQ_LDS_IDX_ACTIVE") / (cycles * n_cu),
+                            "what": "SQ_LDS_IDX_ACTIVE / (cycles x 256 CUs): share of the launch the LDS arrays were busy",
+                            "bank_conflict_share": (get("SQ_LDS_BANK_CONFLICT") or 0.0) / get("SQ_LDS_IDX_ACTIVE")}
+        if get("SQ_WAVE_CYCLES"):
+            units["wave_slots"] = {"frac": 4.0 * get("SQ_WAVE_CYCLES") / (cycles * n_simd * 8),
+                                   "what": "4 x SQ_WAVE_CYCLES / (cycles x 8192 wavefront slots): average occupancy; the kernel's 80 VGPRs allow 6 of 8 per SIMD"}
+        if get("SQ_WAIT_ANY") and get("SQ_WAVE_CYCLES"):
+            units["waiting"] = {"frac": get("SQ_WAIT_ANY") / get("SQ_WAVE_CYCLES"),
+                                "what": "SQ_WAIT_ANY / SQ_WAVE_CYCLES: share of a wavefront's life parked on s_waitcnt"}
+    ms, calls = kernel_avg_ms(tag, walk)
+    out = {"kernel": walk, "round": tag, "kernel_ms_rocprofv3": ms, "kernel_launches_rocprofv3": calls,
+           "shader_cycles_per_launch": cycles}
+    if get("FETCH_SIZE") is not None and get("WRITE_SIZE") is not None:
+        out["hbm_bytes_per_launch"] = (2.0 * get("FETCH_SIZE") + get("WRITE_SIZE")) * 1024.0
+        out["source"] = (f"profiles/{tag}_pmc.md: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), "
+                         "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per MI355X_MICROARCH.md HBM section")
+    if cycles and get("TCP_TCC_READ_REQ_sum"):
+        # a vector-cache -> L2 read request moves one 128-byte line on gfx950 (the records are read as whole lines)
+        l2_bytes = 128.0 * get("TCP_TCC_READ_REQ_sum")
+        secs = (ms or 0.0) * 1e-3
+        units["l2"] = {"bytes_per_launch": l2_bytes, "frac": (l2_bytes / secs / 34.5e12) if secs else None,
+                       "what": "128 B x TCP_TCC_READ_REQ_sum / kernel time against 34.5 TB/s aggregate L2",
+                       "hit_rate": get("TCC_HIT_sum") / (get("TCC_HIT_sum") + get("TCC_MISS_sum")) if get("TCC_HIT_sum") else None}
+    if out.get("hbm_bytes_per_launch") and ms:
+        units["hbm"] = {"frac": out["hbm_bytes_per_launch"] / (ms * 1e-3) / 8.0e12,
+                        "what": "HBM-side bytes / kernel time against 8 TB/s"}
+    out["units"] = units
+    busiest = max(((k, v["frac"]) for k, v in units.items() if k in ("valu", "lds", "l2", "hbm") and v.get("frac")),
+                  key=lambda kv: kv[1], default=None)
+    if busiest:
+        out["limiter"] = {"name": busiest[0], "frac": busiest[1],
+                          "note": "the busiest unit; no unit is saturated - a step is a dependent chain (election -> load -> "
+                                  "LDS -> geometry -> exit) and the resident wavefronts do not cover all of it"}
+    with open(os.path.join(PROF, "roofline.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    lines = [f"walk_composite per launch: {cycles:.4g} shader cycles" if cycles else ""]
+    for k, v in units.items():
+        if v.get("frac") is not None:
+            lines.append(f"  {k}: {v['frac']:.3f}  ({v['what']})")
+    return lines
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     os.makedirs(PROF, exist_ok=True)
@@ -46,7 +111,7 @@ def main():
                 counters[kern][c] = (sum(vals) / len(vals), len(vals))
     lines = [f"# {tag}: rocprofv3 PMC summary (mean per dispatch; separate passes per counter group)", "",
              "Command per pass: `rocprofv3 --pmc <counters> --kernel-trace -d gpurun_out/pmc_X -o pmc --output-format csv "
-             "-- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline`", ""]
+             "-- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-host-image --no-steady`", ""]
     names = sorted({c for k in counters.values() for c in k})
     lines.append("| kernel | " + " | ".join(names) + " |")
     lines.append("|---|" + "---|" * len(names))
@@ -73,6 +138,8 @@ def main():
         if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
             lines.append(f"walk_composite VALU lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) "
                          f"= {c['SQ_THREAD_CYCLES_VALU'][0] / (64 * c['SQ_ACTIVE_INST_VALU'][0]):.3f}")
+    if walk:
+        lines += [""] + write_roofline(tag, walk, counters[walk])
     with open(os.path.join(PROF, f"{tag}_pmc.md"), "w") as f:
         f.write("\n".join(lines) + "\n")
     print("\n".join(lines))

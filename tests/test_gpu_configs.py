@@ -110,7 +110,7 @@ def test_c5_donor_sweep_with_lobe_and_sphere_on_the_1m_grid(gpu_ctx, oracle_port
             nan = np.isnan(img[..., 0])
             assert np.array_equal(nan, np.isnan(ref["image"][..., 0])), k   # NaN mask bit-exact (a9)
             assert np.array_equal(nan, np.isnan(img[..., 1]))
-            assert st["solid_pixels"] == ref["marked"] == int(nan.sum()) > 100_000
+            assert st["solid_pixels"] == ref["marked"] == int(nan.sum()) > 50_000
             # -D turns only the lobe: every other pixel is the solids-free frame, to the bit
             assert np.array_equal(img[~nan].view(np.uint32), bare[~nan].view(np.uint32)), k
             assert st["segments"] < 170_283_916  # rays behind a solid are not walked

@@ -5,10 +5,10 @@
    coordinate before the adjacency is built, and the grid is walked as usual;
  * geometry outside the image domain: plane::get_pixel_by_x/_y clamp the fractional pixel index
    (plane.cpp:194-212), so a face (or the part of a face's row span) that lies wholly beyond a border is
-   smeared onto the border row / column (readme.md:46 "hit outside of domain").  The solid raster and
-   bin_sort_resolve ("algorithm" 1) reproduce that bit for bit; the walk deliberately renders only what is
-   geometrically inside the domain, so it agrees with the reference everywhere except on the outermost
-   rows / columns a smear can reach.
+   smeared onto the border row / column.  The smeared hits arrive in odd numbers, so the reference then
+   nearly always aborts (plane.cpp:39-41, line.cpp:40-47; readme.md:46 "hit outside of domain"): only
+   few-cell solids get through, and for those the solid raster reproduces the smear bit for bit.  For
+   volume grids there is no reference answer; the walk renders what is geometrically inside.
 """
 import numpy as np
 import pytest
@@ -71,8 +71,9 @@ def test_per_cell_point_copies_walk_like_the_indexed_grid(gpu_ctx, oracle_port):
 
 
 def _oracle_or_none(oracle, *args, **kw):
-    """The reference aborts on an odd face-hit count per tet (plane.cpp:39-41) and a clamp smear can
-    produce one: such a scene has no reference answer."""
+    """The reference aborts on an odd face-hit count per tet (plane.cpp:39-41) or a pairing mismatch
+    (line.cpp:40-47), and a clamp smear produces one or the other more often than not: such a scene has no
+    reference answer (readme.md:46 lists "hit outside of domain" as a known crash)."""
     try:
         return oracle.render(*args, **kw)
     except RuntimeError as e:
@@ -82,72 +83,80 @@ def _oracle_or_none(oracle, *args, **kw):
 
 
 def test_solids_across_the_domain_border_smear_like_the_reference(gpu_ctx, oracle_port):
-    """Solid boxes straddling and wholly beyond each border of the domain: the NaN / colour mask must equal
-    the reference's clamp smear (plane.cpp:194-212 via find_intersections_with_polygon, :96-97,126-127)."""
+    """Solid cells straddling and wholly beyond each border of the domain: where the reference renders such
+    a scene at all (every cell's smeared face-hit count has to come out even, plane.cpp:39-41: about one
+    cell in two), the NaN mask must equal its clamp smear bit for bit (plane.cpp:194-212 via
+    find_intersections_with_polygon, :96-97,126-127).  Two-cell solids, seeds searched until three scenes
+    per placement get through the oracle."""
     xyz, cells, alpha, q = mg.workload("g2")
     rots = mg.view_rotations(0.1, 0.07)
     gpu_ctx.upload_grid(xyz, cells, alpha, q)
     b = mg.REFERENCE_BOUNDS  # {x_max, x_min, y_max, y_min} = 2.2, -0.2, 0.9, -0.9
-    compared = 0
+    compared = smeared = 0
     for k, (lo, size) in enumerate([((2.05, -0.3, -0.1), 0.4),    # straddles x_max
                                     ((-0.45, 0.2, 0.0), 0.4),     # straddles x_min
                                     ((0.7, 0.75, -0.2), 0.35),    # straddles y_max
                                     ((1.1, -1.1, 0.1), 0.35),     # straddles y_min
-                                    ((2.3, -0.5, 0.0), 0.3),      # wholly right of x_max: one smeared column
-                                    ((0.3, 1.0, 0.0), 0.25),      # wholly above y_max: smeared onto the last row
+                                    ((2.3, -0.5, 0.0), 0.3),      # wholly right of x_max: smeared onto the last column
+                                    ((0.3, 1.0, 0.0), 0.25),      # wholly above y_max
                                     ((2.0, 0.7, 0.0), 0.5)]):     # the corner
-        sx, sc = mg.kuhn_box(2, lo=lo, size=size, jitter=0.07, seed=20 + k)
-        tets = sx[sc].reshape(-1, 12)
-        ref = _oracle_or_none(oracle_port, xyz, cells, alpha, q, rots, 320, 240, b, solid_tets=tets,
-                              solid_colour=np.full(len(tets), np.nan), threads=8)
-        if ref is None:
-            continue
-        gpu_ctx.set_solid(0, tets, float("nan"))
-        gpu_ctx.set_solid_view(0, np.zeros((0, 3)))
-        img, st = _render(gpu_ctx, rots, 320, 240)
-        assert st["solid_pixels"] == ref["marked"] > 0, (k, st["solid_pixels"], ref["marked"])
-        assert np.array_equal(np.isnan(img), np.isnan(ref["image"])), k
-        assert_images_match(img, ref["image"], f"solid box {k}")
-        compared += 1
-    assert compared >= 5
+        found = 0
+        for seed in range(200):
+            sx, sc = mg.kuhn_box(1, lo=lo, size=size)
+            sx = sx + np.random.default_rng(seed).uniform(-0.03, 0.03, sx.shape)
+            tets = sx[sc[:2]].reshape(-1, 12)
+            ref = _oracle_or_none(oracle_port, xyz, cells, alpha, q, rots, 320, 240, b, solid_tets=tets,
+                                  solid_colour=np.full(len(tets), np.nan), threads=8)
+            if ref is None:
+                continue
+            gpu_ctx.set_solid(0, tets, float("nan"))
+            gpu_ctx.set_solid_view(0, np.zeros((0, 3)))
+            img, st = _render(gpu_ctx, rots, 320, 240)
+            assert st["solid_pixels"] == ref["marked"], (k, seed, st["solid_pixels"], ref["marked"])
+            assert np.array_equal(np.isnan(img), np.isnan(ref["image"])), (k, seed)
+            assert_images_match(img, ref["image"], f"solid cells {k}/{seed}")
+            compared += 1
+            if k == 4:
+                smeared += ref["marked"]
+            found += 1
+            if found == 3:
+                break
+        assert found == 3, k
+    assert compared == 21 and smeared > 0  # cells wholly outside DO mark border pixels, as in the reference
 
 
 def test_volume_grid_across_the_domain_border(gpu_ctx, oracle_port):
-    """A grid that sticks out of the domain on two sides.  bin_sort_resolve ("algorithm" 1) is the
-    reference's own binning including the clamp: equal to the oracle everywhere, smeared border pixels
-    included.  The walk renders only what lies inside the domain: equal to the oracle on every pixel that
-    no smear can reach (all but the outermost rows and columns), and on those it equals its own render of
-    the same scene in a domain widened by one pixel ring (i.e. the geometrically correct value)."""
+    """A volume grid that sticks out of the domain.  The reference has no answer for it: the clamp smear
+    (plane.cpp:194-212) lands faces on border pixels in odd numbers and the run aborts with "odd number of
+    intersections" or the pairing error (plane.cpp:39-41, line.cpp:40-47; readme.md:46 — 0 of 12 000 random
+    six-cell grids across a border got through the oracle).  The walk renders what lies inside the domain:
+    every pixel, the outermost ring included, equals the same ray in a domain one pixel wider on each side,
+    where the grid is cut later; bin_sort_resolve (the reference's binning, which skips what the reference
+    would abort on and counts it in odd_pixels) agrees with the walk away from the ring."""
     rots = mg.view_rotations(0.1, 0.07)
     rx, ry = 300, 220
     b = np.array(mg.REFERENCE_BOUNDS, dtype=np.float64)
-    done = 0
     for k, (lo, size, n) in enumerate([((1.7, 0.3, -0.4), 0.9, 4), ((-0.6, -1.2, -0.3), 0.8, 3), ((1.9, -0.4, -0.2), 0.6, 5)]):
         xyz, cells = mg.kuhn_box(n, lo=lo, size=size, jitter=0.1, seed=40 + k)
         alpha, q = mg.scalars(len(cells), seed=50 + k)
-        ref = _oracle_or_none(oracle_port, xyz, cells, alpha, q, rots, rx, ry, b, threads=8)
-        if ref is None:
-            continue
+        assert _oracle_or_none(oracle_port, xyz, cells, alpha, q, rots, rx, ry, b, threads=8) is None  # the reference aborts
         gpu_ctx.upload_grid(xyz, cells, alpha, q)
-        gpu_ctx.set_option("algorithm", 1)
-        exact, se = _render(gpu_ctx, rots, rx, ry, b)
-        gpu_ctx.set_option("algorithm", 0)
-        assert se["segments"] == ref["segments"] and se["covered_pixels"] == ref["covered"]
-        assert_images_match(exact, ref["image"], f"bin_sort_resolve, grid {k}")
         walk, sw = _render(gpu_ctx, rots, rx, ry, b)
-        assert sw["walk_overflow"] == 0
-        assert_images_match(walk[1:-1, 1:-1], ref["image"][1:-1, 1:-1], f"walk, interior, grid {k}")
-        # the border ring of the walk = the same rays inside a domain one pixel larger on every side
+        assert sw["walk_overflow"] == 0 and sw["segments"] > 0
+        # the same rays inside a domain one pixel larger on every side (coordinates are running sums from
+        # another start: equal to ~1e-13 of a pixel, so the usual tolerance, and a few silhouette pixels may flip)
         sx, sy = (b[0] - b[1]) / (rx - 1), (b[2] - b[3]) / (ry - 1)
         wide = np.array([b[0] + sx, b[1] - sx, b[2] + sy, b[3] - sy])
         big, _ = _render(gpu_ctx, rots, rx + 2, ry + 2, wide)
+        a, c = walk.astype(np.float64), big[1:-1, 1:-1].astype(np.float64)
+        bad = np.abs(a - c) > 1e-5 * np.maximum(np.abs(a), np.abs(c)) + 1e-6 * np.abs(c).max()
+        assert bad.sum() <= 8, (k, int(bad.sum()))
         ring = np.ones((ry, rx), dtype=bool)
         ring[1:-1, 1:-1] = False
-        a, c = walk[ring].astype(np.float64), big[1:-1, 1:-1][ring].astype(np.float64)
-        # (pixel coordinates are running sums from a different start: equal to ~1e-13 of a pixel, so compare
-        # with the usual tolerance and allow the few silhouette pixels that flip)
-        bad = np.abs(a - c) > 1e-5 * np.maximum(np.abs(a), np.abs(c)) + 1e-6 * max(np.abs(c).max(), 1e-30)
-        assert bad.sum() <= 6, (k, int(bad.sum()))
-        assert sw["segments"] <= se["segments"]
-        done += 1
-    assert done >= 2
+        assert walk[ring].any()  # the grid does reach the border
+        gpu_ctx.set_option("algorithm", 1)
+        exact, se = _render(gpu_ctx, rots, rx, ry, b)
+        gpu_ctx.set_option("algorithm", 0)
+        a, c = exact[1:-1, 1:-1].astype(np.float64), walk[1:-1, 1:-1].astype(np.float64)
+        bad = np.abs(a - c) > 1e-5 * np.maximum(np.abs(a), np.abs(c)) + 1e-6 * np.abs(c).max()
+        assert bad.sum() == 0, (k, int(bad.sum()))
