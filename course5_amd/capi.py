@@ -27,6 +27,7 @@ EXPORTS = [
     "c5_render", "c5_render_device", "c5_synchronize", "c5_get_stats", "c5_walk_kernel_ms",
     "c5_download_view_points", "c5_face_adjacency", "c5_set_stream",
     "c5_set_row_range", "c5_get_row_costs", "c5_weld_points",
+    "c5_render_host_async", "c5_render_host_wait", "c5_host_alloc", "c5_host_free", "c5_render_frame_rows_async",
 ]
 
 
@@ -93,6 +94,11 @@ def load_library() -> C.CDLL:
     lib.c5_get_row_costs.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int]
     lib.c5_face_adjacency.argtypes = [ip, C.c_int64, C.c_int64, ip, C.POINTER(C.c_int64)]
     lib.c5_weld_points.argtypes = [dp, C.c_int64, ip, C.POINTER(C.c_int64)]
+    lib.c5_render_host_async.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.c5_render_host_wait.argtypes = [vp]
+    lib.c5_render_frame_rows_async.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.c5_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.c5_host_free.argtypes = [vp, vp]
     for name in EXPORTS:
         if name not in ("c5_destroy", "c5_last_error"):
             getattr(lib, name).restype = C.c_int
@@ -220,6 +226,75 @@ class Context:
     def render_device(self, device_ptr: int):
         """Asynchronous render into device memory (e.g. a torch tensor's data_ptr())."""
         self._check(self.lib.c5_render_device(self.handle, C.c_void_p(device_ptr)))
+
+    # -- frames delivered to host memory, pipelined -------------------------------------------------
+    def host_image(self, full: bool = False) -> np.ndarray:
+        """A pinned float32 [local_rows (or res_y), res_x, 2] image (c5_host_alloc); release with free_host_image."""
+        rows = self.res_y if full else self.local_rows
+        n = rows * self.res_x * 2
+        p = C.c_void_p()
+        self._check(self.lib.c5_host_alloc(self.handle, n * 4, C.byref(p)))
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n,)).reshape(rows, self.res_x, 2)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def free_host_image(self, arr: np.ndarray):
+        p = self._pinned.pop(arr.ctypes.data)
+        self._check(self.lib.c5_host_free(self.handle, p))
+
+    def render_host_async(self, out: np.ndarray):
+        self._check(self.lib.c5_render_host_async(self.handle, out.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def render_frame_rows_async(self, frame: np.ndarray):
+        """This context's rows straight into their places of the full [res_y, res_x, 2] host image."""
+        self._check(self.lib.c5_render_frame_rows_async(self.handle, frame.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def render_host_wait(self) -> int:
+        return self._check(self.lib.c5_render_host_wait(self.handle), allow=(C5_RETRY,))
+
+    def bench_host_frames(self, frames: int, ring: int = 3) -> dict:
+        """Throughput of frames DELIVERED TO HOST MEMORY (what plane::trace_rays returns, plane.cpp:144-172):
+        c5_render_host_async / _wait with `ring` frames in flight into pinned images, plus the plain
+        synchronous c5_render into a pinned and into a pageable image."""
+        import time
+        bufs = [self.host_image() for _ in range(ring)]
+        rays = self.local_rows * self.res_x
+        out = {}
+        try:
+            for attempt in range(3):
+                redo = False
+                for k in range(ring):  # warm
+                    self.render_host_async(bufs[k])
+                for k in range(ring):
+                    redo |= self.render_host_wait() != C5_OK
+                t0 = time.perf_counter()
+                for k in range(frames):
+                    if k >= ring:
+                        redo |= self.render_host_wait() != C5_OK
+                    self.render_host_async(bufs[k % ring])
+                for k in range(min(ring, frames)):
+                    redo |= self.render_host_wait() != C5_OK
+                dt = time.perf_counter() - t0
+                if not redo:
+                    break
+            out["pipelined"] = {"ms_per_frame": round(dt * 1e3 / frames, 4), "value": round(rays * frames / dt / 1e6, 1),
+                                "frames": frames, "in_flight": ring, "destination": "pinned"}
+            for name, dst in (("sync_pinned", bufs[0]), ("sync_pageable", np.empty_like(bufs[0]))):
+                self._check(self.lib.c5_render(self.handle, dst.ctypes.data_as(C.POINTER(C.c_float))))
+                n = max(5, frames // 5)
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    self._check(self.lib.c5_render(self.handle, dst.ctypes.data_as(C.POINTER(C.c_float))))
+                dt = time.perf_counter() - t0
+                out[name] = {"ms_per_frame": round(dt * 1e3 / n, 4), "value": round(rays * n / dt / 1e6, 1), "frames": n}
+            out["unit"] = "Mrays/s"
+            out["what"] = ("the same frames delivered to HOST memory (the image plane::trace_rays returns): PCIe-inclusive, "
+                           "never the headline value")
+        finally:
+            for b in bufs:
+                self.free_host_image(b)
+        return out
 
     def synchronize(self) -> int:
         """Waits for the stream; returns C5_OK or C5_RETRY (frame must be rendered again)."""

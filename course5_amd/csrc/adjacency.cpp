@@ -140,6 +140,20 @@ void parallel_sort(std::vector<T>& v, Less less) {
 }
 }  // namespace
 
+void parallel_copy(void* dst, const void* src, size_t bytes) {
+    const int threads = std::min(host_threads(), 8);
+    if (threads < 2 || bytes < (size_t{1} << 20)) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (int t = 0; t < threads; ++t) {
+        const size_t lo = (bytes * static_cast<size_t>(t) / static_cast<size_t>(threads)) & ~size_t{63};
+        const size_t hi = t + 1 == threads ? bytes : (bytes * static_cast<size_t>(t + 1) / static_cast<size_t>(threads)) & ~size_t{63};
+        std::memcpy(static_cast<char*>(dst) + lo, static_cast<const char*>(src) + lo, hi - lo);
+    }
+}
+
 int64_t weld_points(const double* xyz, int64_t n_pts, std::vector<int32_t>& rep) {
     std::vector<uint32_t> order(static_cast<size_t>(n_pts));
     for (int64_t i = 0; i < n_pts; ++i) order[static_cast<size_t>(i)] = static_cast<uint32_t>(i);

@@ -25,6 +25,7 @@
 #ifndef COURSE5_HIP_H
 #define COURSE5_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -175,12 +176,37 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
 int c5_set_option(c5_context* ctx, const char* name, double value);
 
 /* --- render ---------------------------------------------------------------------------------- */
-/* find_intersections + trace_rays for the local rows.  out_host[local_rows][res_x][2]. */
+/* find_intersections + trace_rays for the local rows.  out_host[local_rows][res_x][2].  Synchronous; retries
+ * by itself on C5_RETRY.  A pinned out_host (c5_host_alloc) receives the image by one direct copy; a pageable
+ * one through pinned staging chunks, copied out on the host threads while the next chunk is in flight. */
 int c5_render(c5_context* ctx, float* out_host);
 /* Same, asynchronous on the context's stream, into device memory (hipMalloc'ed by anyone in
  * this process).  Pair with c5_synchronize. */
 int c5_render_device(c5_context* ctx, void* out_device);
 int c5_synchronize(c5_context* ctx);
+
+/* --- frames delivered to host memory, pipelined ----------------------------------------------------
+ * plane::trace_rays hands back HOST pixels (plane.cpp:144-172); over PCIe Gen5 a 2400x1800 image is
+ * 0.65 ms of transfer beside 0.7 ms of rendering, so the two are overlapped: c5_render_host_async renders
+ * frame k into one of C5_HOST_RING internal device images and copies it to out_host on a copy stream of
+ * its own while frame k + 1 is already being rendered.  out_host should be pinned (c5_host_alloc): a
+ * pageable buffer makes the copy synchronous.  At most C5_HOST_RING frames may be outstanding; every
+ * c5_render_host_async is paired, in order, with one c5_render_host_wait, which returns when THAT frame's
+ * pixels are in out_host.  C5_RETRY from the wait: that frame and every frame enqueued after it are
+ * incomplete (an internal buffer was too small and has been grown) — wait for the rest, discard, render again. */
+#define C5_HOST_RING 3
+int c5_render_host_async(c5_context* ctx, float* out_host);
+int c5_render_host_wait(c5_context* ctx);
+/* The same, but frame_host is the FULL res_y x res_x image shared by all the contexts that render it
+ * (c5_set_row_tiles / c5_set_row_range, one context per GPU): this context's rows are copied straight to
+ * their final places in it — one strided copy over the context's own PCIe link, no exchange between GPUs and
+ * no reassembly (the "N direct copies" of SURVEY.md section 8(e); with 8 GPUs, 8 links instead of the root's one).
+ * Paired with c5_render_host_wait like c5_render_host_async. */
+int c5_render_frame_rows_async(c5_context* ctx, float* frame_host);
+/* Pinned host memory for images (hipHostMalloc / hipHostFree). */
+int c5_host_alloc(c5_context* ctx, size_t bytes, void** out_ptr);
+int c5_host_free(c5_context* ctx, void* ptr);
+
 /* Statistics of the last completed frame (synchronizes). */
 int c5_get_stats(c5_context* ctx, c5_stats* out);
 /* Average duration (ms) of the walk kernel over the launches since the last call with
