@@ -70,7 +70,7 @@ def build_cli(verbose: bool = False, force: bool = False) -> str | None:
     if force or _newer(CLI, deps):
         _run(["g++", "-O3", "-std=c++17", "-Wall", "-Wextra", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(PKG, "..", "include"),
               "-I", "/opt/rocm/include", "-I", host_dir, "-o", CLI] + srcs +
-             [f"-L{PKG}", "-lcourse5_hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN",
+             [f"-L{PKG}", "-lcourse5_hip", "-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-Wl,-rpath,$ORIGIN",
               "-Wl,-rpath,/opt/rocm/lib", "-pthread", "-fopenmp", "-lz"], verbose)
     return CLI
 

@@ -34,6 +34,11 @@ const option_spec kOptions[] = {
     {"alpha_limit", 0, true, "limit alpha value", "2.5"},
     // additions of this build
     {"device", 0, true, "GPU ordinal", "0"},
+    {"devices", 0, true, "several GPUs of this node: 0-7 or 0,1,2 (one context per GPU, grid replicated)", nullptr},
+    {"exchange", 0, true, "several GPUs, rows: host (each GPU copies its rows to the host image), rccl or p2p", "host"},
+    {"split", 0, true, "several GPUs: rows, frames (frame k of a sweep on GPU k mod N) or auto", "auto"},
+    {"bench", 0, true, "render this many sweep frames without writing files and print one JSON line", nullptr},
+    {"bench_warmup", 0, true, "untimed frames before --bench", "20"},
     {"no_solids", 0, false, "do not generate the Roche lobe and the accretor sphere", nullptr},
     {"stats", 0, false, "print per-stage GPU timings and segment counts", nullptr},
     {"raw_vti", 0, false, "write the .vti uncompressed (default: zlib blocks, like vtkXMLImageDataWriter)", nullptr},
@@ -117,6 +122,11 @@ bool program_options(int argc, char** argv, std::ostream& out) {
         else if (n == "initial_system_angle") cfg.system_initial_angle_around_y = to_double(n, v);
         else if (n == "alpha_limit") cfg.limit_alpha_value = to_double(n, v);
         else if (n == "device") cfg.device = static_cast<int>(to_integer(n, v));
+        else if (n == "devices") cfg.devices = v;
+        else if (n == "exchange") cfg.exchange = v;
+        else if (n == "split") cfg.split = v;
+        else if (n == "bench") cfg.bench = static_cast<std::size_t>(std::max(0ll, to_integer(n, v)));
+        else if (n == "bench_warmup") cfg.bench_warmup = static_cast<std::size_t>(std::max(0ll, to_integer(n, v)));
         else if (n == "no_solids") cfg.no_solids = true;
         else if (n == "stats") cfg.print_stats = true;
         else if (n == "raw_vti") cfg.raw_vti = true;
@@ -168,6 +178,11 @@ bool program_options(int argc, char** argv, std::ostream& out) {
         return false;
     }
     if (!cfg.selftest_vti.empty()) return true;
+    if (cfg.bench > 0 && have_file && !have_dest) have_dest = true;  // a benchmark writes no file
+    if (cfg.exchange != "host" && cfg.exchange != "rccl" && cfg.exchange != "p2p")
+        throw std::runtime_error("the argument ('" + cfg.exchange + "') for option '--exchange' is invalid");
+    if (cfg.split != "auto" && cfg.split != "rows" && cfg.split != "frames")
+        throw std::runtime_error("the argument ('" + cfg.split + "') for option '--split' is invalid");
     if (!(have_file && have_dest)) {  // main.cpp:43-51
         out << "Error! Source filename and destination filename must be specified" << std::endl;
         print_usage(out);

@@ -22,6 +22,12 @@ struct render_config {
     double roche_lobe_solid_color = std::numeric_limits<double>::quiet_NaN();
     // additions of this build (all optional)
     int device = 0;
+    std::string devices;          // "0-7", "0,1", ...: several GPUs of one node (overrides --device)
+    std::string exchange = "host";  // how rows rendered by several GPUs come together: host, rccl or p2p (plane.hpp)
+    std::string split = "auto";   // several GPUs: rows (every frame split by rows) or frames (frame k -> GPU k mod N);
+                                  // auto = frames for a sweep, rows for a single frame
+    std::size_t bench = 0;        // > 0: render this many frames of the sweep without writing files, print one JSON line
+    std::size_t bench_warmup = 20;
     bool no_solids = false;
     bool print_stats = false;
     bool parse_only = false;      // read the input, generate the solids, report sizes, no GPU work

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <deque>
 #include <memory>
 #include <iostream>
 #include <limits>
@@ -135,14 +136,44 @@ int main(int argc, char** argv) try {
     if (roche_lobe) objects.push_back(*roche_lobe);
     if (acc_sphere) objects.push_back(*acc_sphere);
 
+    // GPUs: one (the reference's flow as it is) or several of this node.  Several GPUs either split every
+    // frame by rows (config 4: one image, cyclic 16-row tiles) or take whole frames of a sweep in turn
+    // (config 5: frame k on GPU k mod N, nothing to exchange) — frames are independent, rows of a frame too
+    // (plane.cpp:161-169), and the grid is small enough to live on every GPU.
+    const std::vector<int> devices = config.devices.empty() ? std::vector<int>{config.device} : parse_device_list(config.devices);
+    const exchange_mode exchange = config.exchange == "rccl" ? exchange_mode::rccl
+                                   : config.exchange == "p2p" ? exchange_mode::p2p : exchange_mode::host;
+    const bool is_sweep = config.frames > 1 || config.bench > 0;
+    const bool by_frames = devices.size() > 1 && (config.split == "frames" || (config.split == "auto" && is_sweep));
+
     t1 = timestamp();
-    plane base_plane{config.resolution_x, config.resolution_y, objects, domain, config.device};
+    std::vector<std::unique_ptr<plane>> planes;
+    if (by_frames) {
+        planes.resize(devices.size());
+        std::vector<std::thread> makers;
+        std::vector<std::string> errors(devices.size());
+        for (std::size_t d = 0; d < devices.size(); ++d)
+            makers.emplace_back([&, d]() {  // grid upload + adjacency per GPU, side by side
+                try {
+                    planes[d] = std::make_unique<plane>(config.resolution_x, config.resolution_y, objects, domain,
+                                                        std::vector<int>{devices[d]}, exchange_mode::host);
+                } catch (const std::exception& e) {
+                    errors[d] = e.what();
+                }
+            });
+        for (std::thread& t : makers) t.join();
+        for (const std::string& e : errors)
+            if (!e.empty()) throw std::runtime_error(e);
+    } else {
+        planes.push_back(std::make_unique<plane>(config.resolution_x, config.resolution_y, objects, domain, devices, exchange));
+    }
+    plane& base_plane = *planes[0];
     base_plane.find_intersections();
     object2d result = base_plane.trace_rays(tetra_value::alpha, tetra_value::Q);
     t2 = timestamp();
     std::cout << "Ray-tracing completed in " << ms_between(t1, t2) << " ms. " << std::endl;  // main.cpp:131-135
 
-    result.export_to_vti(frame_name(config.destination, 0, config.frames));
+    if (config.bench == 0) result.export_to_vti(frame_name(config.destination, 0, config.frames));
     if (config.print_stats) {
         const c5_stats st = base_plane.stats();
         std::cout << "GPU frame: " << st.ms_total << " ms (transform " << st.ms_transform << ", records " << st.ms_records
@@ -151,21 +182,72 @@ int main(int argc, char** argv) try {
                   << " solid pixels" << std::endl;
     }
 
-    // sweep: the grid, its adjacency and the solids stay on the GPU; only rotation lists change
-    for (std::size_t k = 1; k < config.frames; ++k) {
-        double* angle = config.sweep == "X"   ? &view.angle_around_x
-                        : config.sweep == "D" ? &view.donor_angle
-                        : config.sweep == "I" ? &view.system_initial_angle_around_y
-                                              : &view.angle_around_y;
-        *angle += config.sweep_step;
+    // sweep: the grid, its adjacency and the solids stay on the GPU(s); only rotation lists change.  Frames are
+    // issued ahead (find_intersections returns at once) and retired in order: while frame k is being written,
+    // frames k + 1 ... are rendered and copied to pinned host images.
+    struct pending_frame {
+        std::size_t k;
+        plane* p;
+    };
+    std::deque<pending_frame> in_flight;
+    const std::size_t per_plane = (by_frames || exchange == exchange_mode::host) ? 2 : 1;
+    const std::size_t max_in_flight = per_plane * planes.size();
+    double* const swept = config.sweep == "X"   ? &view.angle_around_x
+                          : config.sweep == "D" ? &view.donor_angle
+                          : config.sweep == "I" ? &view.system_initial_angle_around_y
+                                                : &view.angle_around_y;
+    auto issue = [&](std::size_t k, bool advance) {
+        if (advance) *swept += config.sweep_step;
         apply_view(objects[0], roche_lobe ? &objects[1] : nullptr);
-        base_plane.update_views(objects);
-        base_plane.find_intersections();
-        base_plane.trace_rays(tetra_value::alpha, tetra_value::Q).export_to_vti(frame_name(config.destination, k, config.frames));
-    }
-    if (config.frames > 1) {
-        const auto t3 = timestamp();
-        std::cout << config.frames - 1 << " further frames in " << ms_between(t2, t3) << " ms. " << std::endl;
+        plane* p = planes[k % planes.size()].get();
+        p->update_views(objects);
+        p->find_intersections();
+        in_flight.push_back({k, p});
+    };
+    auto retire = [&](bool write) {
+        const pending_frame f = in_flight.front();
+        in_flight.pop_front();
+        object2d img = f.p->trace_rays(tetra_value::alpha, tetra_value::Q);
+        if (write) img.export_to_vti(frame_name(config.destination, f.k, config.frames));
+    };
+    if (config.bench == 0) {
+        for (std::size_t k = 1; k < config.frames; ++k) {
+            while (in_flight.size() >= max_in_flight) retire(true);
+            issue(k, true);
+        }
+        while (!in_flight.empty()) retire(true);
+        if (config.frames > 1) {
+            const auto t3 = timestamp();
+            std::cout << config.frames - 1 << " further frames in " << ms_between(t2, t3) << " ms. " << std::endl;
+        }
+    } else {
+        // --bench: frames rendered and delivered to host memory, no files.  One JSON line.
+        for (std::size_t k = 0; k < config.bench_warmup; ++k) {
+            while (in_flight.size() >= max_in_flight) retire(false);
+            issue(k, false);
+        }
+        while (!in_flight.empty()) retire(false);
+        std::size_t retries0 = 0;
+        for (const auto& p : planes) retries0 += p->retries();
+        const auto b0 = std::chrono::steady_clock::now();
+        for (std::size_t k = 0; k < config.bench; ++k) {
+            while (in_flight.size() >= max_in_flight) retire(false);
+            issue(k, config.sweep_step != 0.0);
+        }
+        while (!in_flight.empty()) retire(false);
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - b0).count();
+        std::size_t retries1 = 0;
+        for (const auto& p : planes) retries1 += p->retries();
+        const double rays = static_cast<double>(config.resolution_x) * static_cast<double>(config.resolution_y);
+        std::printf("{\"course_bench\": {\"frames\": %zu, \"warmup\": %zu, \"ms_per_frame\": %.4f, \"mrays_per_s\": %.1f, "
+                    "\"res_x\": %zu, \"res_y\": %zu, \"n_devices\": %zu, \"split\": \"%s\", \"exchange\": \"%s\", "
+                    "\"sweep\": \"%s\", \"sweep_step\": %g, \"solids\": %s, \"retries\": %zu, "
+                    "\"delivered_to\": \"pinned host memory\"}}\n",
+                    config.bench, config.bench_warmup, secs * 1e3 / static_cast<double>(config.bench),
+                    rays * static_cast<double>(config.bench) / secs / 1e6, config.resolution_x, config.resolution_y, devices.size(),
+                    devices.size() == 1 ? "none" : (by_frames ? "frames" : "rows"), by_frames ? "none" : config.exchange.c_str(),
+                    config.sweep.c_str(), config.sweep_step, config.no_solids ? "false" : "true", retries1 - retries0);
+        std::fflush(stdout);
     }
     std::cout << "Result exported. Calculations completed." << std::endl;
     return 0;

@@ -1,47 +1,186 @@
 #include "plane.hpp"
 
+#include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is loaded on demand (rccl_api below)
 
+#include <algorithm>
+#include <cstdio>
+#include <iostream>
 #include <stdexcept>
 
 #include "vtk_io.hpp"
 
+namespace {
+constexpr int kTileRows = 16;  // one workgroup row of 8x8 wavefront tiles
+
+void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// librccl.so is half a gigabyte of code objects that the HIP runtime would register at start-up of every
+// single-GPU run: it is opened only when --exchange rccl asks for it.
+struct rccl_api {
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+    bool ok = false;
+    static rccl_api& get() {
+        static rccl_api api = [] {
+            rccl_api a;
+            void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+            if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+            if (!h) {
+                a.error = std::string("cannot load librccl: ") + dlerror();
+                return a;
+            }
+            auto sym = [&](const char* name) {
+                void* p = dlsym(h, name);
+                if (!p && a.error.empty()) a.error = std::string("librccl lacks ") + name;
+                return p;
+            };
+            a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(sym("ncclCommInitAll"));
+            a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+            a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
+            a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
+            a.Send = reinterpret_cast<decltype(a.Send)>(sym("ncclSend"));
+            a.Recv = reinterpret_cast<decltype(a.Recv)>(sym("ncclRecv"));
+            a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+            a.ok = a.error.empty();
+            return a;
+        }();
+        return api;
+    }
+};
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// pinned images
+// ------------------------------------------------------------------------------------------------
+image_pool::~image_pool() {
+    for (float* p : _free) (void)hipHostFree(p);
+}
+
+std::shared_ptr<float> image_pool::take() {
+    float* p = nullptr;
+    if (!_free.empty()) {
+        p = _free.back();
+        _free.pop_back();
+    } else {
+        hip_check(hipHostMalloc(reinterpret_cast<void**>(&p), _bytes ? _bytes : 1, hipHostMallocDefault), "hipHostMalloc of an image");
+    }
+    std::weak_ptr<image_pool> home = shared_from_this();
+    return std::shared_ptr<float>(p, [home](float* q) {
+        if (auto pool = home.lock())
+            pool->_free.push_back(q);
+        else
+            (void)hipHostFree(q);
+    });
+}
+
 void object2d::export_to_vti(const std::string& filename) const {
-    write_vti(filename, _pixels.data(), static_cast<int>(_res_x), static_cast<int>(_res_y),
+    write_vti(filename, _pixels.get(), static_cast<int>(_res_x), static_cast<int>(_res_y),
               !app::instance().config.raw_vti);
 }
 
-void plane::check(int rc, const char* what) {
+std::vector<int> parse_device_list(const std::string& text) {
+    std::vector<int> out;
+    std::size_t pos = 0;
+    while (pos <= text.size()) {
+        const std::size_t comma = std::min(text.find(',', pos), text.size());
+        const std::string part = text.substr(pos, comma - pos);
+        if (part.empty()) throw std::runtime_error("bad device list '" + text + "'");
+        const std::size_t dash = part.find('-');
+        try {
+            if (dash == std::string::npos) {
+                out.push_back(std::stoi(part));
+            } else {
+                const int a = std::stoi(part.substr(0, dash)), b = std::stoi(part.substr(dash + 1));
+                if (b < a) throw std::runtime_error("descending range");
+                for (int d = a; d <= b; ++d) out.push_back(d);
+            }
+        } catch (const std::exception&) {
+            throw std::runtime_error("bad device list '" + text + "'");
+        }
+        pos = comma + 1;
+    }
+    if (out.empty()) throw std::runtime_error("empty device list");
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device-side exchange (rccl / p2p): per-device strips, the root's full image, communicators
+// ------------------------------------------------------------------------------------------------
+struct multi_gpu {
+    std::vector<int> devices;
+    std::vector<hipStream_t> stream;
+    std::vector<hipEvent_t> done;
+    std::vector<float*> strip;
+    std::vector<int> n_rows;   // local rows per device
+    float* root_frame = nullptr;
+    std::vector<ncclComm_t> comm;
+    bool rccl_ready = false;
+    std::string rccl_note;
+
+    ~multi_gpu() {
+        for (std::size_t r = 0; r < devices.size(); ++r) {
+            (void)hipSetDevice(devices[r]);
+            if (r < comm.size() && comm[r]) (void)rccl_api::get().CommDestroy(comm[r]);
+            if (r < strip.size() && strip[r]) (void)hipFree(strip[r]);
+            if (r < done.size() && done[r]) (void)hipEventDestroy(done[r]);
+            if (r < stream.size() && stream[r]) (void)hipStreamDestroy(stream[r]);
+        }
+        if (root_frame) {
+            (void)hipSetDevice(devices[0]);
+            (void)hipFree(root_frame);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// plane
+// ------------------------------------------------------------------------------------------------
+void plane::check(int rc, const char* what, std::size_t dev) {
     if (rc == C5_OK) return;
     // the reference throws std::runtime_error from the same places (plane.cpp:40,152,263,270)
-    throw std::runtime_error(std::string(what) + ": " + c5_last_error(_ctx));
+    throw std::runtime_error(std::string(what) + ": " + c5_last_error(dev < _ctx.size() ? _ctx[dev] : nullptr));
 }
 
 plane::plane(std::size_t res_x, std::size_t res_y, std::vector<object3d_base> objects3d,
-             std::vector<double> global_boundaries, int device) {
+             std::vector<double> global_boundaries, std::vector<int> devices, exchange_mode exchange)
+    : _devices(std::move(devices)), _exchange(exchange) {
     if (!global_boundaries.empty() && global_boundaries.size() != 4)
         throw std::runtime_error("plane initializer. wrong manual boundaries");  // plane.cpp:262-264
     if (objects3d.empty())
         throw std::runtime_error("plane initializer. empty set of objects to render");  // plane.cpp:269-271
     if (global_boundaries.empty())
         throw std::runtime_error("plane initializer. automatic boundaries are not supported: pass {x_max, x_min, y_max, y_min}");
+    if (_devices.empty()) throw std::runtime_error("plane initializer. no GPU given");
     _x = res_x;
     _y = res_y;
-
-    const int rc = c5_create(device, &_ctx);
-    if (rc != C5_OK) throw std::runtime_error(std::string("c5_create: ") + c5_last_error(nullptr));
+    const int world = static_cast<int>(_devices.size());
 
     // volume grids are merged into one indexed grid (the reference concatenates tetra vectors,
     // plane.cpp:290-293); solids keep one slot each, in order
     std::vector<double> pts, a, q;
     std::vector<int32_t> cells;
+    struct solid_ref {
+        const object3d_data* d;
+        int slot;
+    };
+    std::vector<solid_ref> solids;
     int next_slot = 0;
     for (object3d_base& obj : objects3d) {
         const object3d_data& d = *obj.get_pointer();
         if (d.kind == tetra_type::solid) {
             if (next_slot >= C5_MAX_SOLIDS) throw std::runtime_error("too many solid objects");
-            check(c5_set_solid(_ctx, next_slot, d.soup.data(), static_cast<int64_t>(d.soup.size() / 12), d.colour),
-                  "c5_set_solid");
+            solids.push_back({&d, next_slot});
             _slot_of_object.push_back(next_slot++);
         } else {
             const int32_t base = static_cast<int32_t>(pts.size() / 3);
@@ -52,67 +191,258 @@ plane::plane(std::size_t res_x, std::size_t res_y, std::vector<object3d_base> ob
             _slot_of_object.push_back(-1);
         }
     }
-    if (!cells.empty())
-        check(c5_upload_grid(_ctx, pts.data(), static_cast<int64_t>(pts.size() / 3), cells.data(),
-                             static_cast<int64_t>(cells.size() / 4), a.data(), q.data()),
-              "c5_upload_grid");
-    check(c5_set_image(_ctx, static_cast<int>(res_x), static_cast<int>(res_y), global_boundaries.data()), "c5_set_image");
-    check(c5_set_alpha_limit(_ctx, app::instance().config.limit_alpha_value), "c5_set_alpha_limit");  // line.cpp:204
-    if (app::instance().config.reference_algorithm) check(c5_set_option(_ctx, "algorithm", 1.0), "c5_set_option");
+    _views.solids.resize(static_cast<std::size_t>(next_slot));
+
+    // one context per device, the grid replicated (52 MB at 1M cells; pixels are independent,
+    // plane.cpp:161-169, so nothing but the image is ever exchanged)
+    for (int r = 0; r < world; ++r) {
+        c5_context* ctx = nullptr;
+        if (c5_create(_devices[static_cast<std::size_t>(r)], &ctx) != C5_OK)
+            throw std::runtime_error(std::string("c5_create: ") + c5_last_error(nullptr));
+        _ctx.push_back(ctx);
+        const std::size_t k = static_cast<std::size_t>(r);
+        for (const solid_ref& s : solids)
+            check(c5_set_solid(ctx, s.slot, s.d->soup.data(), static_cast<int64_t>(s.d->soup.size() / 12), s.d->colour),
+                  "c5_set_solid", k);
+        if (!cells.empty())
+            check(c5_upload_grid(ctx, pts.data(), static_cast<int64_t>(pts.size() / 3), cells.data(),
+                                 static_cast<int64_t>(cells.size() / 4), a.data(), q.data()),
+                  "c5_upload_grid", k);
+        if (world > 1) check(c5_set_row_tiles(ctx, kTileRows, r, world), "c5_set_row_tiles", k);
+        check(c5_set_image(ctx, static_cast<int>(res_x), static_cast<int>(res_y), global_boundaries.data()), "c5_set_image", k);
+        check(c5_set_alpha_limit(ctx, app::instance().config.limit_alpha_value), "c5_set_alpha_limit", k);  // line.cpp:204
+        if (app::instance().config.reference_algorithm) check(c5_set_option(ctx, "algorithm", 1.0), "c5_set_option", k);
+    }
     update_views(objects3d);
-    if (hipMalloc(&_device_image, res_x * res_y * 2 * sizeof(float)) != hipSuccess)
-        throw std::runtime_error("hipMalloc of the output image failed");
+    _pool = std::make_shared<image_pool>(res_x * res_y * 2 * sizeof(float));
+
+    if (_exchange != exchange_mode::host) {
+        _mg = std::make_unique<multi_gpu>();
+        multi_gpu& m = *_mg;
+        m.devices = _devices;
+        m.stream.assign(_devices.size(), nullptr);
+        m.done.assign(_devices.size(), nullptr);
+        m.strip.assign(_devices.size(), nullptr);
+        m.n_rows.assign(_devices.size(), 0);
+        for (std::size_t r = 0; r < _devices.size(); ++r) {
+            hip_check(hipSetDevice(_devices[r]), "hipSetDevice");
+            hip_check(hipStreamCreateWithFlags(&m.stream[r], hipStreamNonBlocking), "hipStreamCreate");
+            hip_check(hipEventCreateWithFlags(&m.done[r], hipEventDisableTiming), "hipEventCreate");
+            check(c5_set_stream(_ctx[r], m.stream[r]), "c5_set_stream", r);
+            check(c5_local_rows(_ctx[r], &m.n_rows[r]), "c5_local_rows", r);
+            const std::size_t bytes = static_cast<std::size_t>(m.n_rows[r]) * res_x * 2 * sizeof(float);
+            hip_check(hipMalloc(reinterpret_cast<void**>(&m.strip[r]), bytes ? bytes : 8), "hipMalloc of a strip");
+            if (r > 0 && _devices[r] != _devices[0]) {
+                const hipError_t e = hipDeviceEnablePeerAccess(_devices[0], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) hip_check(e, "hipDeviceEnablePeerAccess");
+                (void)hipGetLastError();
+            }
+        }
+        hip_check(hipSetDevice(_devices[0]), "hipSetDevice");
+        hip_check(hipMalloc(reinterpret_cast<void**>(&m.root_frame), res_x * res_y * 2 * sizeof(float)), "hipMalloc of the root image");
+        if (_exchange == exchange_mode::rccl && world > 1) {
+            rccl_api& nccl = rccl_api::get();
+            if (!nccl.ok) {
+                m.rccl_note = nccl.error + " - exchanging by peer copies instead";
+            } else {
+                m.comm.assign(_devices.size(), nullptr);
+                const ncclResult_t rc = nccl.CommInitAll(m.comm.data(), world, _devices.data());
+                if (rc == ncclSuccess) {
+                    m.rccl_ready = true;
+                } else {
+                    // e.g. the same GPU named twice (a rehearsal on one GPU): RCCL refuses duplicate devices
+                    m.comm.clear();
+                    m.rccl_note = std::string("ncclCommInitAll: ") + nccl.GetErrorString(rc) + " - exchanging by peer copies instead";
+                }
+            }
+            if (!m.rccl_ready) std::cerr << "course: " << m.rccl_note << std::endl;
+        }
+    }
 }
 
 plane::~plane() {
-    if (_ctx) {
-        c5_synchronize(_ctx);
-        c5_destroy(_ctx);
+    for (std::size_t r = 0; r < _ctx.size(); ++r) {
+        if (!_ctx[r]) continue;
+        while (_exchange == exchange_mode::host && !_flight.empty()) {  // nothing may still be copying into a pooled image
+            for (c5_context* c : _ctx) (void)c5_render_host_wait(c);
+            _flight.pop_front();
+        }
+        (void)c5_synchronize(_ctx[r]);
     }
-    if (_device_image) (void)hipFree(_device_image);
+    _mg.reset();
+    for (c5_context* c : _ctx)
+        if (c) c5_destroy(c);
+}
+
+void plane::send_views(const views_t& v) {
+    for (std::size_t r = 0; r < _ctx.size(); ++r) {
+        check(c5_set_view(_ctx[r], v.grid.data(), static_cast<int>(v.grid.size())), "c5_set_view", r);
+        for (std::size_t s = 0; s < v.solids.size(); ++s)
+            check(c5_set_solid_view(_ctx[r], static_cast<int>(s), v.solids[s].data(), static_cast<int>(v.solids[s].size())),
+                  "c5_set_solid_view", r);
+    }
 }
 
 void plane::update_views(std::vector<object3d_base>& objects3d) {
     bool grid_view_set = false;
     for (std::size_t k = 0; k < objects3d.size() && k < _slot_of_object.size(); ++k) {
         const object3d_data& d = *objects3d[k].get_pointer();
-        const int n = static_cast<int>(d.rotations.size());
         if (_slot_of_object[k] < 0) {
-            if (!grid_view_set) check(c5_set_view(_ctx, d.rotations.data(), n), "c5_set_view");
+            if (!grid_view_set) _views.grid = d.rotations;
             grid_view_set = true;
         } else {
-            check(c5_set_solid_view(_ctx, _slot_of_object[k], d.rotations.data(), n), "c5_set_solid_view");
+            _views.solids[static_cast<std::size_t>(_slot_of_object[k])] = d.rotations;
         }
+    }
+    send_views(_views);
+}
+
+void plane::start(frame_t& f) {
+    for (std::size_t r = 0; r < _ctx.size(); ++r) {
+        if (_exchange == exchange_mode::host)
+            check(c5_render_frame_rows_async(_ctx[r], f.image.get()), "find_intersections", r);
+        else
+            check(c5_render_device(_ctx[r], _mg->strip[r]), "find_intersections", r);
     }
 }
 
 void plane::find_intersections() {
-    int rc = c5_render_device(_ctx, _device_image);
-    check(rc, "find_intersections");
-    _in_flight = true;
+    const std::size_t limit = _exchange == exchange_mode::host ? C5_HOST_RING : 1;
+    if (_flight.size() >= limit)
+        throw std::runtime_error("find_intersections: " + std::to_string(limit) + " frame(s) already in flight, call trace_rays first");
+    frame_t f;
+    f.image = _pool->take();
+    f.views = _views;
+    start(f);
+    _flight.push_back(std::move(f));
+}
+
+// rccl / p2p: every strip is known complete (status checked) before anything is exchanged; every tile lands
+// at its final offset of the root GPU's image; one copy from there to the host.
+void plane::finish_exchange(frame_t& f) {
+    multi_gpu& m = *_mg;
+    const int world = static_cast<int>(_ctx.size());
+    for (std::size_t r = 0; r < _ctx.size(); ++r) {
+        int rc = c5_synchronize(_ctx[r]);
+        for (int attempt = 0; rc == C5_RETRY && attempt < 3; ++attempt) {  // an internal buffer grew: this device renders again
+            ++_retries;
+            check(c5_render_device(_ctx[r], m.strip[r]), "trace_rays", r);
+            rc = c5_synchronize(_ctx[r]);
+        }
+        check(rc, "trace_rays", r);
+    }
+    const std::size_t row_floats = _x * 2, tile_floats = row_floats * kTileRows;
+    const std::size_t row_bytes = row_floats * sizeof(float), tile_bytes = tile_floats * sizeof(float);
+    const int n_tiles = static_cast<int>((_y + kTileRows - 1) / kTileRows);
+    auto rows_of_tile = [&](int gt) { return std::min<std::size_t>(kTileRows, _y - static_cast<std::size_t>(gt) * kTileRows); };
+    auto copy_own_tiles = [&](std::size_t r, hipStream_t s) {  // 2-D copy: one "row" of it = one tile
+        const int whole = m.n_rows[r] / kTileRows, rest = m.n_rows[r] - whole * kTileRows;
+        float* const first = m.root_frame + tile_floats * r;
+        if (world == 1) {
+            hip_check(hipMemcpyAsync(m.root_frame, m.strip[r], row_bytes * m.n_rows[r], hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+            return;
+        }
+        if (whole > 0)
+            hip_check(hipMemcpy2DAsync(first, tile_bytes * world, m.strip[r], tile_bytes, tile_bytes, static_cast<std::size_t>(whole),
+                                       hipMemcpyDeviceToDevice, s), "hipMemcpy2DAsync");
+        if (rest > 0)
+            hip_check(hipMemcpyAsync(first + tile_floats * world * whole, m.strip[r] + tile_floats * whole, row_bytes * rest,
+                                     hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+    };
+    if (_exchange == exchange_mode::rccl && m.rccl_ready) {
+        rccl_api& nccl = rccl_api::get();
+        ncclResult_t rc = nccl.GroupStart();
+        for (int gt = 0; gt < n_tiles && rc == ncclSuccess; ++gt) {
+            const int r = gt % world, lt = gt / world;
+            if (r == 0) continue;
+            const std::size_t count = rows_of_tile(gt) * row_floats;
+            rc = nccl.Send(m.strip[static_cast<std::size_t>(r)] + tile_floats * lt, count, ncclFloat, 0,
+                          m.comm[static_cast<std::size_t>(r)], m.stream[static_cast<std::size_t>(r)]);
+            if (rc == ncclSuccess)
+                rc = nccl.Recv(m.root_frame + tile_floats * gt, count, ncclFloat, r, m.comm[0], m.stream[0]);
+        }
+        const ncclResult_t end = nccl.GroupEnd();
+        if (rc != ncclSuccess || end != ncclSuccess)
+            throw std::runtime_error(std::string("RCCL exchange failed: ") + nccl.GetErrorString(rc != ncclSuccess ? rc : end));
+        hip_check(hipSetDevice(_devices[0]), "hipSetDevice");
+        copy_own_tiles(0, m.stream[0]);
+    } else {
+        for (std::size_t r = 0; r < _ctx.size(); ++r) {
+            hip_check(hipSetDevice(_devices[r]), "hipSetDevice");
+            copy_own_tiles(r, m.stream[r]);  // runs on the sending device's stream, writes the root's memory
+            if (r > 0) hip_check(hipEventRecord(m.done[r], m.stream[r]), "hipEventRecord");
+        }
+        hip_check(hipSetDevice(_devices[0]), "hipSetDevice");
+        for (std::size_t r = 1; r < _ctx.size(); ++r) hip_check(hipStreamWaitEvent(m.stream[0], m.done[r], 0), "hipStreamWaitEvent");
+    }
+    hip_check(hipMemcpyAsync(f.image.get(), m.root_frame, _x * _y * 2 * sizeof(float), hipMemcpyDeviceToHost, m.stream[0]),
+              "hipMemcpyAsync to the host");
+    hip_check(hipStreamSynchronize(m.stream[0]), "hipStreamSynchronize");
 }
 
 object2d plane::trace_rays(tetra_value value_alpha, tetra_value value_Q) {
     if (value_alpha != tetra_value::alpha || value_Q != tetra_value::Q)
         throw std::runtime_error("trace_rays: only (alpha, Q) is supported");
-    if (!_in_flight) find_intersections();
-    int rc = c5_synchronize(_ctx);
-    for (int attempt = 0; rc == C5_RETRY && attempt < 3; ++attempt) {  // an internal buffer grew: redo the frame
-        check(c5_render_device(_ctx, _device_image), "trace_rays");
-        rc = c5_synchronize(_ctx);
+    if (_flight.empty()) find_intersections();
+    if (_exchange != exchange_mode::host) {
+        finish_exchange(_flight.front());
+    } else {
+        for (int attempt = 0;; ++attempt) {
+            bool retry = false;
+            for (std::size_t r = 0; r < _ctx.size(); ++r) {
+                const int rc = c5_render_host_wait(_ctx[r]);
+                if (rc == C5_RETRY)
+                    retry = true;
+                else
+                    check(rc, "trace_rays", r);
+            }
+            if (!retry) break;
+            // An internal buffer was too small for this frame: it and every frame enqueued since are suspect
+            // on every device.  Let them all finish, then render them again, in order, each with its own views.
+            if (attempt >= 3) throw std::runtime_error("trace_rays: frames kept being reported incomplete");
+            ++_retries;
+            for (std::size_t k = 1; k < _flight.size(); ++k)
+                for (std::size_t r = 0; r < _ctx.size(); ++r) {
+                    const int rc = c5_render_host_wait(_ctx[r]);
+                    if (rc != C5_RETRY) check(rc, "trace_rays", r);
+                }
+            for (frame_t& f : _flight) {
+                send_views(f.views);
+                start(f);
+            }
+            send_views(_views);
+        }
     }
-    check(rc, "trace_rays");
-    _in_flight = false;
-    std::vector<float> pixels(_x * _y * 2);
-    if (hipMemcpy(pixels.data(), _device_image, pixels.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
-        throw std::runtime_error("copying the image from the GPU failed");
-    return object2d(std::move(pixels), _x, _y);
+    frame_t f = std::move(_flight.front());
+    _flight.pop_front();
+    return object2d(std::move(f.image), _x, _y);
 }
 
 c5_stats plane::stats() {
-    c5_stats st{};
-    check(c5_get_stats(_ctx, &st), "c5_get_stats");
-    return st;
+    c5_stats sum{};
+    for (std::size_t r = 0; r < _ctx.size(); ++r) {
+        c5_stats st{};
+        int rc = c5_get_stats(_ctx[r], &st);
+        if (rc == C5_RETRY) rc = C5_OK;  // frames in flight behind the last completed one: theirs to report
+        check(rc, "c5_get_stats", r);
+        sum.segments += st.segments;
+        sum.covered_pixels += st.covered_pixels;
+        sum.solid_pixels += st.solid_pixels;
+        sum.entries += st.entries;
+        sum.steps += st.steps;
+        sum.pool_entries += st.pool_entries;
+        sum.odd_pixels += st.odd_pixels;
+        sum.walk_overflow += st.walk_overflow;
+        sum.boundary_faces = st.boundary_faces;
+        sum.pool_capacity = st.pool_capacity;
+        sum.ms_transform = std::max(sum.ms_transform, st.ms_transform);
+        sum.ms_records = std::max(sum.ms_records, st.ms_records);
+        sum.ms_entries = std::max(sum.ms_entries, st.ms_entries);
+        sum.ms_solids = std::max(sum.ms_solids, st.ms_solids);
+        sum.ms_walk = std::max(sum.ms_walk, st.ms_walk);
+        sum.ms_total = std::max(sum.ms_total, st.ms_total);
+    }
+    return sum;
 }
 
 std::size_t plane::count_all_intersections() { return static_cast<std::size_t>(stats().segments); }

@@ -1,8 +1,11 @@
 // `plane` and `object2d` with the reference's public interface (plane.hpp:17-33, object2d.hpp:13-22),
-// implemented on the C ABI of libcourse5_hip.so instead of the OpenMP pixel loops.
+// implemented on the C ABI of libcourse5_hip.so instead of the OpenMP pixel loops, on one GPU or on
+// several GPUs of one node (one c5_context and one stream per device, this one process driving them all).
 #pragma once
 
 #include <cstdint>
+#include <deque>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -10,54 +13,107 @@
 #include "course5_hip.h"
 #include "scene.hpp"
 
+// Pinned host images, recycled: a 2400x1800 frame is 34.6 MB, and pinning memory costs milliseconds.
+class image_pool : public std::enable_shared_from_this<image_pool> {
+public:
+    explicit image_pool(std::size_t bytes) : _bytes(bytes) {}
+    ~image_pool();
+    std::shared_ptr<float> take();  // returned to the pool when the last owner lets go
+    std::size_t bytes() const { return _bytes; }
+
+private:
+    std::size_t _bytes;
+    std::vector<float*> _free;
+};
+
 // Two-channel fp32 image, row-major [y][x][2] (the order export_to_vti writes, object2d.cpp:17-21).
 class object2d {
 public:
     object2d() = default;
     object2d(std::vector<float> pixels, std::size_t res_x, std::size_t res_y)
-        : _pixels(std::move(pixels)), _res_x(res_x), _res_y(res_y) {}
+        : _owned(std::make_shared<std::vector<float>>(std::move(pixels))), _res_x(res_x), _res_y(res_y) {
+        _pixels = std::shared_ptr<float>(_owned, _owned->data());
+    }
+    object2d(std::shared_ptr<float> pinned, std::size_t res_x, std::size_t res_y)
+        : _pixels(std::move(pinned)), _res_x(res_x), _res_y(res_y) {}
     void export_to_vti(const std::string& filename) const;  // object2d.cpp:7-29
-    float at(std::size_t x, std::size_t y, std::size_t channel) const { return _pixels[(y * _res_x + x) * 2 + channel]; }
+    float at(std::size_t x, std::size_t y, std::size_t channel) const { return _pixels.get()[(y * _res_x + x) * 2 + channel]; }
     std::size_t res_x() const { return _res_x; }
     std::size_t res_y() const { return _res_y; }
-    const std::vector<float>& data() const { return _pixels; }
+    const float* data() const { return _pixels.get(); }
 
 private:
-    std::vector<float> _pixels;
+    std::shared_ptr<std::vector<float>> _owned;
+    std::shared_ptr<float> _pixels;
     std::size_t _res_x = 0, _res_y = 0;
 };
+
+// How the rows rendered by several GPUs come together:
+//   host  every GPU copies its row tiles straight to their places in the pinned host image over its OWN
+//         PCIe link (c5_render_frame_rows_async): no exchange between GPUs, no reassembly, frames pipelined.
+//         The default: plane::trace_rays hands back host pixels (plane.cpp:144-172) anyway.
+//   rccl  grouped ncclSend / ncclRecv over xGMI, every tile received at its final offset of the root GPU's
+//         full image, then one copy to the host from there (north star: "RCCL gather of tile strips");
+//   p2p   the same exchange as peer-to-peer 2-D copies (hipMemcpy2DAsync, the copy engines instead of a kernel).
+enum class exchange_mode { host, rccl, p2p };
+
+struct multi_gpu;  // RCCL communicators, peer access, per-device strips (plane.cpp)
 
 class plane {
 public:
     plane() = delete;
     // plane.cpp:260-315.  objects3d: volume grids (transparent) and solids, in the reference's order;
     // global_boundaries = {x_max, x_min, y_max, y_min} (required here: the reference's automatic
-    // bounding box is never used by its own main, main.cpp:83,127).
+    // bounding box is never used by its own main, main.cpp:83,127).  devices: GPU ordinals, one context
+    // each; with more than one the image rows are dealt to them in cyclic tiles of 16 rows.
     explicit plane(std::size_t res_x, std::size_t res_y, std::vector<object3d_base> objects3d,
-                   std::vector<double> global_boundaries = {}, int device = 0);
+                   std::vector<double> global_boundaries = {}, std::vector<int> devices = {0},
+                   exchange_mode exchange = exchange_mode::host);
     ~plane();
     plane(const plane&) = delete;
     plane& operator=(const plane&) = delete;
 
-    // plane.cpp:184-192: starts the frame on the GPU (view transform, records, entries, solids, walk)
+    // plane.cpp:184-192: starts a frame on the GPU(s) (view transform, records, entries, solids, walk) and
+    // its way to host memory; returns at once.  Up to C5_HOST_RING frames may be in flight.
     void find_intersections();
-    // plane.cpp:144-172: waits for the frame and returns the image.  The two signatures select the
-    // cell values for ch0/ch1 as in the reference; only (alpha, Q) is meaningful there and here.
+    // plane.cpp:144-172: waits for the OLDEST frame in flight and returns its image.  The two arguments
+    // select the cell values for ch0/ch1 as in the reference; only (alpha, Q) is meaningful there and here.
     object2d trace_rays(tetra_value value_alpha, tetra_value value_Q);
-    std::size_t count_all_intersections();  // plane.cpp:3-12 (segments of the last frame)
+    std::size_t count_all_intersections();  // plane.cpp:3-12 (segments of the last frame, all devices)
 
     std::size_t get_x() const { return _x; }
     std::size_t get_y() const { return _y; }
+    std::size_t frames_in_flight() const { return _flight.size(); }
+    std::size_t retries() const { return _retries; }
 
     // Re-send the objects' rotation lists (a sweep changes only these; the grid stays on the GPU).
     void update_views(std::vector<object3d_base>& objects3d);
-    c5_stats stats();
+    c5_stats stats();  // of the last completed frame: counts summed over the devices, times of the slowest
 
 private:
-    void check(int rc, const char* what);
-    c5_context* _ctx = nullptr;
+    struct views_t {
+        std::vector<c5_rotation> grid;
+        std::vector<std::vector<c5_rotation>> solids;  // by solid slot
+    };
+    struct frame_t {
+        std::shared_ptr<float> image;
+        views_t views;
+    };
+    void check(int rc, const char* what, std::size_t dev = 0);
+    void send_views(const views_t& v);
+    void start(frame_t& f);                 // enqueue on every device
+    void finish_exchange(frame_t& f);       // rccl / p2p: strips -> root image -> host (synchronous)
+    std::vector<c5_context*> _ctx;
+    std::vector<int> _devices;
+    exchange_mode _exchange = exchange_mode::host;
     std::size_t _x = 0, _y = 0;
     std::vector<int> _slot_of_object;  // -1: part of the volume grid, >= 0: solid slot
-    void* _device_image = nullptr;
-    bool _in_flight = false;
+    views_t _views;
+    std::deque<frame_t> _flight;
+    std::shared_ptr<image_pool> _pool;
+    std::unique_ptr<multi_gpu> _mg;
+    std::size_t _retries = 0;
 };
+
+// "0", "0-7", "0,2,4", "0,0" (the same GPU twice: rehearsal of the multi-GPU path on one GPU)
+std::vector<int> parse_device_list(const std::string& text);

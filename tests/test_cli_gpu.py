@@ -104,3 +104,67 @@ def test_course_donor_sweep_moves_only_the_lobe(tmp_path, oracle_port):
         assert_images_match(got, ref["image"], f"donor frame {k}")
         masks.append(np.isnan(got[..., 0]))
     assert not np.array_equal(masks[0], masks[1]) and not np.array_equal(masks[1], masks[2])
+
+
+def _run(args, timeout=600):
+    r = subprocess.run([COURSE] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    return r
+
+
+@pytest.mark.parametrize("exchange", ["host", "p2p", "rccl"])
+def test_course_splits_a_frame_by_rows_over_several_contexts(tmp_path, exchange):
+    """`course --devices`: one process, one c5_context per listed GPU, cyclic 16-row tiles, every tile
+    delivered at its final offset (host: each GPU copies its rows into the pinned host image; p2p / rccl:
+    into the root GPU's image first).  The test box has one GPU, so the list names it three times: everything
+    runs except the RCCL transport itself, which refuses duplicate devices — the run must say so and fall
+    back to peer copies.  Output equals the single-GPU file value for value; 450 rows leave a short last tile."""
+    xyz, cells, a, q = mg.workload("c2")
+    src = tmp_path / "c2.vtk"
+    mg.write_vtk_binary(str(src), xyz, cells, a, q)
+    common = ["-f", src, "-x", 600, "-y", 450, "-X", 0.1, "-Y", 0.07, "-D", 0.3, "--raw_vti", "-j4"]
+    _run(common + ["-d", tmp_path / "one.vti"])
+    r = _run(common + ["-d", tmp_path / "many.vti", "--devices", "0,0,0", "--exchange", exchange, "--split", "rows", "--stats"])
+    one, _ = vtkio.read_vti(str(tmp_path / "one.vti"))
+    many, _ = vtkio.read_vti(str(tmp_path / "many.vti"))
+    assert np.array_equal(one, many, equal_nan=True)
+    assert np.isnan(one).any() and (one[~np.isnan(one)] > 0).any()
+    if exchange == "rccl":
+        assert "exchanging by peer copies instead" in r.stderr
+    segs = [int(w) for line in r.stdout.splitlines() if "segments" in line for w in [line.split(";")[1].split()[0]]]
+    assert segs and segs[0] > 0
+
+
+def test_course_deals_the_frames_of_a_sweep_to_several_contexts(tmp_path):
+    """Frame-parallel sweep (BASELINE config 5 on several GPUs): frame k on context k mod N, each with the
+    grid and the solids resident, frames issued ahead and written in order.  Every file equals the one the
+    single-context sweep writes."""
+    xyz, cells, a, q = mg.workload("g2")
+    src = tmp_path / "g2.vtk"
+    mg.write_vtk_ascii(str(src), xyz, cells, a, q)
+    common = ["-f", src, "-x", 400, "-y", 300, "-X", 0.1, "-Y", 0.07, "--frames", 7, "--sweep", "D", "--sweep_step", 0.11,
+              "--raw_vti", "-j4"]
+    _run(common + ["-d", tmp_path / "a.vti"])
+    _run(common + ["-d", tmp_path / "b.vti", "--devices", "0,0,0"])
+    masks = []
+    for k in range(7):
+        one, _ = vtkio.read_vti(str(tmp_path / f"a_{k:05d}.vti"))
+        many, _ = vtkio.read_vti(str(tmp_path / f"b_{k:05d}.vti"))
+        assert np.array_equal(one, many, equal_nan=True), k
+        masks.append(np.isnan(one[..., 0]))
+    assert all(not np.array_equal(masks[0], m) for m in masks[1:])
+
+
+def test_course_bench_prints_one_json_line(tmp_path):
+    import json
+    xyz, cells, a, q = mg.workload("g2")
+    src = tmp_path / "g2.vtk"
+    mg.write_vtk_ascii(str(src), xyz, cells, a, q)
+    for extra, split in ((["--devices", "0,0"], "frames"), (["--devices", "0,0", "--split", "rows"], "rows"), ([], "none")):
+        r = _run(["-f", src, "-x", 640, "-y", 480, "-X", 0.1, "-Y", 0.07, "--no_solids", "--bench", 30, "--bench_warmup", 5,
+                  "--sweep", "Y"] + extra)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"course_bench"')]
+        assert len(line) == 1
+        b = json.loads(line[0])["course_bench"]
+        assert b["frames"] == 30 and b["split"] == split and b["mrays_per_s"] > 10 and b["retries"] == 0
+        assert not list(tmp_path.glob("*.vti"))
