@@ -76,6 +76,7 @@ def parse():
     p.add_argument("--backend", default="nccl", help="nccl (= RCCL, default); gloo only to rehearse N > 1 on one GPU")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-host-image", action="store_true", help="skip the second figure: frames delivered to host memory")
+    p.add_argument("--no-native", action="store_true", help="skip the figures of the C++ host (`course --bench`)")
     p.add_argument("--no-steady", action="store_true", help="skip the clock-steadying frames after the W warm-up steps (profiling passes)")
     p.add_argument("--cpu-sample-res", default="", help="image size of the CPU baseline (default: the benchmark's own)")
     p.add_argument("--pipeline-depth", type=int, default=2, help="N > 1: frames whose exchange may be in flight")
@@ -144,6 +145,39 @@ def product_solids():
         soups.append(np.frombuffer(raw, dtype=np.float64, count=12 * n, offset=off + 8).reshape(n, 12))
         off += 8 + 96 * n
     return soups
+
+
+def native_course_bench(xyz, cells, alpha, q, res_x, res_y, n_devices, frames, warmup, variants):
+    """The C++ host (`course`, one process driving every GPU through one c5_context each) on the same grid,
+    view and image: frames rendered and delivered to pinned host memory, no files.  Secondary figures; a
+    failure here is recorded, never fatal."""
+    import subprocess
+    import tempfile
+    out = {}
+    exe = os.path.join(ROOT, "course5_amd", "course")
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            src = os.path.join(d, "grid.vtk")
+            mg.write_vtk_binary(src, xyz, cells, alpha, q, v51=True)
+            devs = ",".join(str(k) for k in range(n_devices)) if not os.environ.get("C5_BENCH_ONE_DEVICE") else ",".join(["0"] * n_devices)
+            for name, extra in variants:
+                cmd = [exe, "-f", src, "--no_solids", "-x", str(res_x), "-y", str(res_y), "-X", str(mg.BENCH_VIEW["angle_around_x"]),
+                       "-Y", str(mg.BENCH_VIEW["angle_around_y"]), "--bench", str(frames), "--bench_warmup", str(warmup),
+                       "--sweep", "Y", "--sweep_step", "0", "--devices", devs] + extra
+                try:
+                    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+                    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"course_bench"')]
+                    if r.returncode == 0 and line:
+                        out[name] = json.loads(line[0])["course_bench"]
+                        if "instead" in r.stderr:
+                            out[name]["note"] = [ln for ln in r.stderr.splitlines() if "instead" in ln][0]
+                    else:
+                        out[name] = {"error": (r.stderr or r.stdout)[-300:]}
+                except Exception as e:  # noqa: BLE001
+                    out[name] = {"error": repr(e)[:300]}
+    except Exception as e:  # noqa: BLE001
+        out["error"] = repr(e)[:300]
+    return out
 
 
 def main():
@@ -331,6 +365,26 @@ def main():
     if world == 1 and not args.no_host_image and hasattr(ctx, "render_host_async"):
         host_image = ctx.bench_host_frames(min(args.steps, 100))
 
+    # The C++ host on the same workload: rank 0 runs it as a child process on all N GPUs while the other ranks
+    # idle at the barrier below (their GPUs are free: nothing of this job is running on them).
+    native = None
+    if not args.no_native and not args.solids and args.sweep == "none" and args.workload == "c3":
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            k = max(20, min(args.steps, 200))
+            if world == 1:
+                variants = [("one_gpu", [])]
+            else:
+                variants = [("rows_host", ["--split", "rows", "--exchange", "host"]),
+                            ("rows_rccl", ["--split", "rows", "--exchange", "rccl"]),
+                            ("rows_p2p", ["--split", "rows", "--exchange", "p2p"]),
+                            ("frames", ["--split", "frames"])]
+            native = native_course_bench(xyz, cells, alpha, q, res_x, res_y, world, k, 20, variants)
+        if world > 1:
+            dist.barrier()
+
     el = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
     seg = torch.tensor([stats["segments"], n_local * res_x, retries], dtype=torch.int64, device=rdev)
     wk = torch.tensor([walk_ms], dtype=torch.float64, device=rdev)
@@ -412,6 +466,10 @@ def main():
         }
         if host_image is not None:
             out["value_host_image"] = host_image
+        if native is not None:
+            out["native_host"] = {"what": "the C++ host `course --bench` (one process, one c5_context per GPU) on the same grid, "
+                                          "view and image; frames delivered to pinned host memory; Mrays/s in mrays_per_s",
+                                  **native}
         if world == 1 and not args.no_cpu_baseline:
             sres = tuple(int(v) for v in args.cpu_sample_res.lower().split("x")) if args.cpu_sample_res else (res_x, res_y)
             out["cpu_baseline"], _ = cpu_baseline(xyz, cells, alpha, q, rots, sres)
