@@ -26,6 +26,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wex
 LIB_SOURCES = [
     ("exact_kernels.hip", ["-ffp-contract=off"]),   # must round like the reference's host build
     ("walk_kernels.hip", []),
+    ("walk_mixed.hip", []),
     ("c_api.hip", []),
     ("adjacency.cpp", ["-x", "c++", "-fopenmp"]),
 ]

@@ -71,6 +71,7 @@ constexpr size_t kCountersBytes = sizeof(c5::FrameCounters) * c5::kCounterShards
 // while walk_composite of frame k (VALU / address-path bound) runs on the main stream.
 struct FrameSlot {
     DeviceBuffer vx, vy, vz, rec, opt, count, head, first, pool, mask, counters, row_cost;
+    DeviceBuffer geo, opt32, z0;  // "precision" 1: compact records (allocated on first use)
     int64_t entry_capacity = 0;
     bool head_clean = false;  // the per-pixel entry heads are all zero (the walk kernels leave them so)
     c5::FrameCounters* host_counters = nullptr;  // pinned
@@ -123,6 +124,7 @@ struct c5_context {
     int lds_pad = 0;
     int band_rows = 0;
     int order = 0;
+    int precision = 0;  // 0: fp64 walk, bit-faithful (default); 1: fp32 geometry + fp64 accumulators (walk_mixed.hip)
     int lds_stage = 1;
     int stage_timing = 1;
     int walk_timing = 1;
@@ -400,7 +402,27 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
         C5_HIP(ctx, hipEventRecord(ctx->fork_ev, s));
         C5_HIP(ctx, hipStreamWaitEvent(e, ctx->fork_ev, 0));
     }
-    c5::launch_build_records(s, g, ctx->alpha_limit, ctx->order);
+    // "precision" 1 needs the LDS-staged walk's preconditions and its own limits; otherwise the fp64 walk serves
+    const bool mixed = ctx->precision == 1 && c5::mixed_precision_fits(ctx->n_cells, im);
+    if (mixed) {
+        const size_t nc = static_cast<size_t>(ctx->n_cells);
+        if (fs.geo.bytes < nc * sizeof(c5::GeoRecord) + 64) {
+            // records of cells outside a context's row band are never rebuilt: whatever they hold must be a valid
+            // record (zeros: neighbour ids inside the grid)
+            C5_HIP(ctx, fs.geo.ensure(nc * sizeof(c5::GeoRecord) + 64));
+            C5_HIP(ctx, fs.opt32.ensure(nc * sizeof(c5::OptRecord) + 16));
+            C5_HIP(ctx, fs.z0.ensure(nc * sizeof(float) + 4));
+            C5_HIP(ctx, hipMemsetAsync(fs.geo.ptr, 0, fs.geo.bytes, s));
+            C5_HIP(ctx, hipMemsetAsync(fs.opt32.ptr, 0, fs.opt32.bytes, s));
+            C5_HIP(ctx, hipMemsetAsync(fs.z0.ptr, 0, fs.z0.bytes, s));
+        }
+        g.geo = fs.geo.as<c5::GeoRecord>();
+        g.opt32 = fs.opt32.as<c5::OptRecord>();
+        g.z0 = fs.z0.as<float>();
+        c5::launch_build_records_mixed(s, g, im, ctx->xtab.as<double>(), ctx->ytab.as<double>(), ctx->alpha_limit, ctx->order);
+    } else {
+        c5::launch_build_records(s, g, ctx->alpha_limit, ctx->order);
+    }
     C5_HIP(ctx, mark(2, s));
     // boundary entries: one raster pass (per-pixel count + first entry + overflow chain)
     if (!fs.head_clean) C5_HIP(ctx, hipMemsetAsync(fs.head.ptr, 0, static_cast<size_t>(padded) * sizeof(c5::EntryHead), e));
@@ -426,6 +448,10 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     c5::WalkParams wp{};
     wp.rec = g.rec;
     wp.opt = g.opt;
+    wp.geo = g.geo;
+    wp.opt32 = g.opt32;
+    wp.z0 = g.z0;
+    wp.precision = mixed ? 1 : 0;
     wp.entry_head = fs.head.as<c5::EntryHead>();
     wp.entry_first = fs.first.as<c5::Entry>();
     wp.entry_pool = fs.pool.as<c5::Entry>();
@@ -471,7 +497,10 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
         ev_slot = ctx->walk_used++;
         C5_HIP(ctx, hipEventRecord(ctx->walk_a[ev_slot], main_s));
     }
-    c5::launch_walk(main_s, wp, ctx->tile_shape);
+    if (mixed)
+        c5::launch_walk_mixed(main_s, wp, ctx->tile_shape);
+    else
+        c5::launch_walk(main_s, wp, ctx->tile_shape);
     fs.head_clean = true;  // stream order: every pixel's head is zero again once the walk has run
     if (ev_slot >= 0) C5_HIP(ctx, hipEventRecord(ctx->walk_b[ev_slot], main_s));
     C5_HIP(ctx, mark(5, main_s));
@@ -689,7 +718,7 @@ void c5_destroy(c5_context* ctx) {
     for (DeviceBuffer* b : bufs) b->release();
     for (FrameSlot& fs : ctx->slots) {
         DeviceBuffer* sb[] = {&fs.vx, &fs.vy, &fs.vz, &fs.rec, &fs.opt, &fs.count, &fs.head, &fs.first, &fs.pool,
-                              &fs.mask, &fs.counters, &fs.row_cost};
+                              &fs.mask, &fs.counters, &fs.row_cost, &fs.geo, &fs.opt32, &fs.z0};
         for (DeviceBuffer* b : sb) b->release();
         if (fs.host_counters) (void)hipHostFree(fs.host_counters);
         for (auto& ev : fs.ev)
@@ -801,6 +830,9 @@ int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int3
         // valid record (neighbour ids inside the grid) from the start
         C5_HIP(ctx, hipMemset(fs.rec.ptr, 0, fs.rec.bytes));
         C5_HIP(ctx, hipMemset(fs.opt.ptr, 0, fs.opt.bytes));
+        fs.geo.release();  // "precision" 1 records of the old grid: rebuilt (and zeroed) on first use
+        fs.opt32.release();
+        fs.z0.release();
     }
     C5_HIP(ctx, ctx->cell_vert.ensure(cb * 16 + 16));
     C5_HIP(ctx, ctx->cell_adj.ensure(cb * 16 + 16));
@@ -1026,6 +1058,9 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
         ctx->lds_stage = static_cast<int>(value) != 0;
     } else if (n == "integration") {
         ctx->order = static_cast<int>(value) != 0;
+    } else if (n == "precision") {
+        if (value != 0 && value != 1) return fail(ctx, C5_ERR_INVALID, "precision must be 0 (fp64) or 1 (mixed)");
+        ctx->precision = static_cast<int>(value);
     } else if (n == "entry_pool") {  // testing: (re)size the overflow pool of the entry lists, in records
         if (value < 1 || value > 16777214) return fail(ctx, C5_ERR_INVALID, "entry_pool out of range");
         int rc = drain(ctx);

@@ -20,6 +20,10 @@ struct GridView {  // device pointers of the persistent grid + per-view buffers
     const uint32_t* bface = nullptr;
     CellRecord* rec = nullptr;
     CellOptics* opt = nullptr;
+    // "precision" 1 (walk_mixed.hip): compact single-precision records instead of rec / opt
+    GeoRecord* geo = nullptr;
+    OptRecord* opt32 = nullptr;
+    float* z0 = nullptr;
     // only cells whose projected y-extent meets [cull_y_lo, cull_y_hi] can be reached by a ray of this context
     double cull_y_lo = 0, cull_y_hi = 0;
 };
@@ -27,6 +31,10 @@ struct GridView {  // device pointers of the persistent grid + per-view buffers
 struct WalkParams {
     const CellRecord* rec;
     const CellOptics* opt;
+    const GeoRecord* geo;       // "precision" 1
+    const OptRecord* opt32;
+    const float* z0;
+    int32_t precision;          // 0: fp64 walk (bit-faithful), 1: walk_composite_mixed
     EntryHead* entry_head;      // [n_local_px] entries of the pixel + overflow chain; the walk hands it back zeroed
     const Entry* entry_first;   // [n_local_px] first entry (valid where entry_count > 0)
     const Entry* entry_pool;    // overflow entries, chained from entry_first[].next
@@ -78,5 +86,11 @@ void launch_entry_lists(hipStream_t s, const GridView& g, const double* Xtab, co
                         const ImageParams& im, EntryHead* head, Entry* first, Entry* pool, int64_t capacity,
                         FrameCounters* counters, unsigned* sticky, int want_upper);
 void launch_walk(hipStream_t s, const WalkParams& p, int tile_shape);
+
+// walk_mixed.hip ("precision" 1)
+void launch_build_records_mixed(hipStream_t s, const GridView& g, const ImageParams& im, const double* Xtab,
+                                const double* Ytab, double alpha_limit, int order);
+void launch_walk_mixed(hipStream_t s, const WalkParams& p, int tile_shape);
+bool mixed_precision_fits(int64_t n_cells, const ImageParams& im);
 
 }  // namespace c5

@@ -1,0 +1,461 @@
+// "precision" 1: the walk with single-precision geometry and double-precision accumulators.
+//
+// The fp64 walk (walk_kernels.hip) reproduces the reference to the last bit of its fp32 output; it reads
+// 160 bytes per step and spends most of its vector instructions at the fp64 rate.  This variant keeps what the
+// 1e-5 bar of the north star needs and no more:
+//   * per cell 64 bytes of geometry (GeoRecord: four face planes in fp32 about an origin on the pixel lattice
+//     close to the cell, so fp32 resolves 1e-7 of the CELL, not of the domain) + 16 bytes of optics: half the
+//     L2 / LDS traffic per step, one staging load instruction for sixteen cells instead of two for eight each;
+//   * face depths, the z_top / z_bot pairing (line.cpp:99-131) and the exit face in fp32 (v_min3 / v_max3);
+//   * exp(-alpha dz) - 1 by a short fp32 series while |alpha dz| < 1/8 (always, on grids that resolve the
+//     image), the general fp64 exp otherwise (one wave-uniform branch);
+//   * tau and I accumulate in fp64:  tau += dz alpha (line.cpp:189);  I += (I - Q/alpha)(e^{-alpha dz} - 1),
+//     which is line.cpp:220-224's  I = (Q - (Q - alpha I) e^{-alpha dz}) / alpha  rearranged.
+// Per-chord error ~1e-7 relative, uncorrelated between cells; images agree with the reference to ~1e-6
+// (tests: every golden vector, the fuzz sweep and the full C3 frame against the oracle, all at the 1e-5 bar).
+// What it gives up: bit-equality with the fp64 walk, and with it the exact segment COUNT — a ray within
+// ~1e-9 of a projected edge may count a sliver the reference does not (or the other way round).
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+#include "device_types.hpp"
+#include "kernels.hpp"
+#include "walk_common.hpp"
+
+namespace c5 {
+
+bool mixed_precision_fits(int64_t n_cells, const ImageParams& im) {
+    // 32-bit byte offsets into the 64-byte records; the lattice origin holds 16 bits per axis
+    return n_cells < (int64_t{1} << 26) && im.res_x <= 65535 && im.res_y <= 65535;
+}
+
+// ------------------------------------------------------------------------------------------
+// build_records_mixed: one thread per cell.  The planes are the fp64 ones of build_records (same
+// classification, same walk order, same neighbour words), re-expressed about the lattice origin and narrowed.
+// ------------------------------------------------------------------------------------------
+struct alignas(16) F4 {
+    float a, b, c, d;
+};
+struct alignas(16) U4 {
+    uint32_t a, b, c, d;
+};
+
+__global__ __launch_bounds__(256) void build_records_mixed(GridView g, ImageParams im, const double* __restrict__ Xtab,
+                                                           const double* __restrict__ Ytab, double alpha_limit, int order) {
+    const int64_t cell = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (cell >= g.n_cells) return;
+    CellRecord r;
+    CellOptics o;
+    if (!build_cell(g, alpha_limit, order, cell, r, o)) return;  // outside this context's row band
+
+    // origin: the pixel nearest (x0, y0), clamped to the image (a cell outside the domain is never walked)
+    const double fc = rint((r.x0 - im.x_min) / im.step_x), fr = rint((r.y0 - im.y_min) / im.step_y);
+    const int col0 = static_cast<int>(fmin(fmax(fc, 0.0), im.res_x - 1.0));
+    const int row0 = static_cast<int>(fmin(fmax(fr, 0.0), im.res_y - 1.0));
+    const double ox = Xtab[col0] - r.x0, oy = Ytab[row0] - r.y0;
+    double c0[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c0[k] = fma(r.plane[k][1], ox, fma(r.plane[k][2], oy, r.plane[k][0]));  // depth of plane k at the origin
+    // depth origin: a finite plane's depth at the lattice origin (slot 0 is an upper face unless the cell is flat)
+    const double zref = (fabs(c0[0]) <= DBL_MAX) ? c0[0] : ((fabs(c0[3]) <= DBL_MAX) ? c0[3] : 0.0);
+    const float z0f = static_cast<float>(zref);
+    GeoRecord out;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        out.plane[k][0] = static_cast<float>(c0[k] - static_cast<double>(z0f));  // +-inf stays +-inf
+        out.plane[k][1] = static_cast<float>(r.plane[k][1] * im.step_x);
+        out.plane[k][2] = static_cast<float>(r.plane[k][2] * im.step_y);
+    }
+    const uint32_t n_up = r.nbr[0] >> kUpperCountShift;
+    const int first = (order == 0) ? 0 : 1;  // exit candidates: slots 0..2 walking up, 1..3 walking down
+    out.w[0] = (r.nbr[first] & kIdMask) | (n_up << kUpperCountShift);
+    out.w[1] = r.nbr[first + 1] & kIdMask;
+    out.w[2] = r.nbr[first + 2] & kIdMask;
+    out.w[3] = static_cast<uint32_t>(col0) | (static_cast<uint32_t>(row0) << 16);
+
+    const U4* src = reinterpret_cast<const U4*>(&out);
+    U4* dst = reinterpret_cast<U4*>(g.geo + cell);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[k] = src[k];
+    OptRecord q;
+    q.alpha_raw = static_cast<float>(o.alpha_raw);
+    q.alpha_c = static_cast<float>(o.alpha_c);
+    q.source = (o.alpha_c != 0.0) ? static_cast<float>(o.q / o.alpha_c) : 0.0f;
+    q.pad = 0.0f;
+    *reinterpret_cast<F4*>(g.opt32 + cell) = *reinterpret_cast<const F4*>(&q);
+    g.z0[cell] = z0f;
+}
+
+void launch_build_records_mixed(hipStream_t s, const GridView& g, const ImageParams& im, const double* Xtab,
+                                const double* Ytab, double alpha_limit, int order) {
+    if (g.n_cells <= 0) return;
+    const unsigned blocks = static_cast<unsigned>((g.n_cells + 255) / 256);
+    hipLaunchKernelGGL(build_records_mixed, dim3(blocks), dim3(256), 0, s, g, im, Xtab, Ytab, alpha_limit, order);
+}
+
+// ------------------------------------------------------------------------------------------
+// walk_composite_mixed
+// ------------------------------------------------------------------------------------------
+constexpr int kMixSlots = 16;        // distinct cells staged per wavefront and step: ONE load instruction
+constexpr int kMixStride = 5;        // 16-byte units per slot: 4 of GeoRecord + 1 of OptRecord.  80 bytes = 20
+                                     // banks: sixteen slots start on sixteen different 16-byte bank columns
+constexpr unsigned kMixBuckets = 256;
+
+using V4F = float __attribute__((ext_vector_type(4)));
+using V4U = uint32_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float min3_f32(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max3_f32(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// e^x - 1 for -1/8 < x <= 0 in fp32: x (1 + x/2 (1 + x/3 (...))) to x^7 (truncation 5e-10 relative)
+__device__ __forceinline__ float expm1_small(float x) {
+    float p = fmaf(x, 1.0f / 5040.0f, 1.0f / 720.0f);
+    p = fmaf(p, x, 1.0f / 120.0f);
+    p = fmaf(p, x, 1.0f / 24.0f);
+    p = fmaf(p, x, 1.0f / 6.0f);
+    p = fmaf(p, x, 0.5f);
+    p = fmaf(p, x, 1.0f);
+    return p * x;
+}
+
+template <int TILE, int ORDER>
+__global__ __launch_bounds__(256, 6) void walk_composite_mixed(WalkParams P) {
+    using TS = TileShape<TILE>;
+    constexpr int TW = TS::WW * TS::GX, TH = TS::WH * TS::GY;
+    constexpr bool kUp = (ORDER == 0);
+    __shared__ V4F s_stage[4][kMixSlots * kMixStride];
+    __shared__ int s_elect[4][kMixBuckets + 128];  // leader tables of 256 and 64 buckets + the cell id of every slot
+    __shared__ double s_scur[4][64];
+
+    const ImageParams& im = P.im;
+    const int tiles_x = (im.res_x + TW - 1) / TW;
+    const int tiles_y = (im.n_local_rows + TH - 1) / TH;
+    int tx, ty;
+    if (P.xcd_mode == 0) {
+        ty = blockIdx.x / tiles_x;
+        tx = blockIdx.x - ty * tiles_x;
+    } else {
+        // square super-blocks of S x S workgroups dealt round-robin to the 8 XCDs (walk_composite_lds)
+        const int S = P.band_tiles;
+        const int sbx_n = (tiles_x + S - 1) / S, sby_n = (tiles_y + S - 1) / S;
+        const int xcd = blockIdx.x & 7;
+        const int seq = blockIdx.x >> 3;
+        const int sb = (seq / (S * S)) * 8 + xcd;
+        const int within = seq - (seq / (S * S)) * (S * S);
+        if (sb >= sbx_n * sby_n) return;
+        const int sby = sb / sbx_n, sbx = sb - sby * sbx_n;
+        ty = sby * S + within / S;
+        tx = sbx * S + (within - (within / S) * S);
+        if (tx >= tiles_x || ty >= tiles_y) return;
+    }
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = tx * TW + (wave % TS::GX) * TS::WW + (lane % TS::WW);
+    const int lrow = ty * TH + (wave / TS::GX) * TS::WH + (lane / TS::WW);
+    auto pixel_index = [&]() { return static_cast<size_t>(lrow) * im.res_x + col; };
+    const bool in_image = (col < im.res_x) && (lrow < im.n_local_rows);
+    V4F* const my_stage = s_stage[wave];
+    int* const my_elect = s_elect[wave];
+    double* const my_scur = s_scur[wave];
+    const char* const geo_bytes = reinterpret_cast<const char*>(P.geo);
+    const char* const opt_bytes = reinterpret_cast<const char*>(P.opt32);
+
+    constexpr unsigned kOverflowBit = 0x80000000u;
+    unsigned n_seg = 0;
+    unsigned n_step_wave = 0;
+    double tau = 0.0, I = 0.0, T = 1.0;
+    int grow = 0;  // global image row of this lane's pixel
+    int nb = -1;
+
+    {
+        size_t lp = 0;
+        uint32_t mv = 0;
+        EntryHead ent{0, 0};
+        if (in_image) {
+            lp = pixel_index();
+            mv = P.mask ? P.mask[lp] : 0u;
+            ent = load_entry_head(P.entry_head + lp);
+        }
+        if (__builtin_amdgcn_ballot_w64(mv != 0u || ent.count != 0) == 0ull) {  // neither grid nor solid: zeros, done
+            if (in_image) {
+                __builtin_nontemporal_store(0.f, &P.out[lp].x);
+                __builtin_nontemporal_store(0.f, &P.out[lp].y);
+            }
+            return;
+        }
+        if (in_image && !mv) {
+            grow = global_row_of(im, lrow);
+            double s_cur = DBL_MAX;
+            if (ent.count > 0) nb = next_entry<kUp>(P, lp, ent, s_cur);
+            my_scur[lane] = s_cur;
+        }
+    }
+    my_elect[kMixBuckets + 64 + lane] = 0;  // slot ids: always a valid cell id
+
+    // the contribution of the step just taken waits here while the next records are in flight
+    bool pend = false;
+    float pend_dz = 0.0f;
+    V4F pend_opt = {0.0f, 0.0f, 0.0f, 0.0f};  // {alpha_raw, alpha_c, source, -}
+
+    const uint32_t geo_piece_off = static_cast<uint32_t>(lane & 3) * 16u;
+    const int gslot = lane >> 2;  // slot whose geometry piece this lane loads
+    V4F* const put_geo = my_stage + gslot * kMixStride + (lane & 3);
+    V4F* const put_opt = my_stage + (lane & 15) * kMixStride + 4;
+
+    for (unsigned iter = 0;; ++iter) {
+        const bool need = nb >= 0;
+        const unsigned long long needs = __builtin_amdgcn_ballot_w64(need);
+        if (needs == 0ull) break;
+        if (iter >= P.max_steps) {
+            if (need) n_seg |= kOverflowBit;
+            break;
+        }
+        n_step_wave += static_cast<unsigned>(__popcll(needs));
+
+        // 1. one slot per DISTINCT cell: leader election through a hashed table in LDS (walk_composite_lds)
+        const unsigned unb = static_cast<unsigned>(nb);
+        const unsigned h1 = (unb ^ (unb >> 8)) & (kMixBuckets - 1u);
+        const int ticket = static_cast<int>((unb << 6) | static_cast<unsigned>(lane));  // ids of this kernel have 26 bits
+        if (need) my_elect[h1] = ticket;
+        __builtin_amdgcn_wave_barrier();
+        const int won = my_elect[h1];
+        __builtin_amdgcn_wave_barrier();
+        int w = won & 63;
+        const bool other = (static_cast<unsigned>(won) >> 6) != unb;
+        const bool open = need && other;
+        if ((__builtin_amdgcn_ballot_w64(other) & needs) != 0ull) {
+            const unsigned t = unb >> 6;
+            const unsigned h2 = (unb + t + (t << 2) + (unb >> 12)) & 63u;
+            if (open) my_elect[kMixBuckets + h2] = ticket;
+            __builtin_amdgcn_wave_barrier();
+            const int won2 = my_elect[kMixBuckets + h2];
+            __builtin_amdgcn_wave_barrier();
+            if (open) w = ((static_cast<unsigned>(won2) >> 6) == unb) ? (won2 & 63) : lane;
+        }
+        const unsigned long long heads =
+            __builtin_amdgcn_uicmp(static_cast<unsigned>(w), static_cast<unsigned>(lane), 32 /* eq */) & needs;
+        const int n_runs = __builtin_popcountll(heads);
+        const int rank = static_cast<int>(__builtin_amdgcn_mbcnt_hi(
+            static_cast<uint32_t>(heads >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(heads), 0u)));
+        if (need && w == lane) my_elect[kMixBuckets + 64 + rank] = nb;
+        const int slot = __builtin_amdgcn_ds_bpermute(w << 2, rank);
+        __builtin_amdgcn_wave_barrier();
+        const int n_staged = __builtin_amdgcn_readfirstlane(n_runs < kMixSlots ? n_runs : kMixSlots);
+
+        // 2. cooperative loads: 4 lanes x 16 B per GeoRecord (all sixteen slots in ONE instruction), lanes 0-15
+        //    one OptRecord each
+        const uint32_t idg = static_cast<uint32_t>(my_elect[kMixBuckets + 64 + gslot]);
+        const V4F stage_g = *reinterpret_cast<const V4F*>(geo_bytes + ((idg << 6) | geo_piece_off));
+        V4F stage_o = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (lane < 16) {
+            const uint32_t ido = static_cast<uint32_t>(my_elect[kMixBuckets + 64 + lane]);
+            stage_o = *reinterpret_cast<const V4F*>(opt_bytes + (ido << 4));
+        }
+
+        // ... while they are in flight: emission / absorption of the step just taken.
+        //     I' = I + (I - S)(e^{-alpha dz} - 1)  ==  (Q - (Q - alpha I) e^{-alpha dz}) / alpha   (line.cpp:220-224)
+        {
+            const float xarg = -(pend_opt.y * pend_dz);
+            const bool big_arg = pend && !(xarg > -0.125f);
+            if (__builtin_amdgcn_ballot_w64(big_arg) == 0ull) {
+                if (pend) {
+                    const double em1 = static_cast<double>(expm1_small(xarg));
+                    const double S = static_cast<double>(pend_opt.z);
+                    if (ORDER == 0) {
+                        I = fma(I - S, em1, I);
+                    } else if (T >= P.t_cutoff) {
+                        I = fma(-(T * S), em1, I);  // + T S (1 - e)
+                        T = fma(T, em1, T);         // T e
+                    }
+                }
+            } else if (pend) {
+                const double e = exp_nonpositive(static_cast<double>(xarg));
+                const double S = static_cast<double>(pend_opt.z);
+                if (ORDER == 0) {
+                    if (pend_opt.y != 0.0f) I = fma(I - S, e - 1.0, I);
+                } else if (T >= P.t_cutoff) {
+                    I = fma(T * S, 1.0 - e, I);
+                    T *= e;
+                }
+            }
+            pend = false;
+        }
+
+        // 3. park the pieces in LDS
+        __builtin_amdgcn_wave_barrier();
+        if (gslot < n_staged) *put_geo = stage_g;
+        if (lane < n_staged) *put_opt = stage_o;  // (n_staged <= 16)
+        __builtin_amdgcn_wave_barrier();
+
+        // 4. every ray fetches its cell
+        if (need) {
+            V4F g0, g1, g2, o;
+            V4U gw;
+            if (slot < kMixSlots) {
+                const V4F* r = reinterpret_cast<const V4F*>(reinterpret_cast<const char*>(my_stage) +
+                                                            __umul24(static_cast<unsigned>(slot), kMixStride * 16u));
+                g0 = r[0];
+                g1 = r[1];
+                g2 = r[2];
+                gw = *reinterpret_cast<const V4U*>(r + 3);
+                o = r[4];
+            } else {  // more distinct cells than slots: rare in 8x8 tiles
+                const V4F* r = reinterpret_cast<const V4F*>(P.geo + nb);
+                g0 = r[0];
+                g1 = r[1];
+                g2 = r[2];
+                gw = *reinterpret_cast<const V4U*>(r + 3);
+                o = *reinterpret_cast<const V4F*>(P.opt32 + nb);
+            }
+            // planes (c, gx, gy): g0.xyz | g0.w g1.xy | g1.zw g2.x | g2.yzw
+            const float dcol = static_cast<float>(col - static_cast<int>(gw.w & 0xFFFFu));
+            const float drow = static_cast<float>(grow - static_cast<int>(gw.w >> 16));
+            const float z0 = fmaf(g0.y, dcol, fmaf(g0.z, drow, g0.x));
+            const float z1 = fmaf(g1.x, dcol, fmaf(g1.y, drow, g0.w));
+            const float z2 = fmaf(g1.w, dcol, fmaf(g2.x, drow, g1.z));
+            const float z3 = fmaf(g2.z, dcol, fmaf(g2.w, drow, g2.y));
+            const uint32_t n_up = gw.x >> kUpperCountShift;  // 1..3: slot 0 always upper, slot 3 always lower
+            const bool up1 = n_up > 1u, up2 = n_up > 2u;
+            const float u1 = up1 ? z1 : INFINITY, l1 = up1 ? -INFINITY : z1;
+            const float u2 = up2 ? z2 : INFINITY, l2 = up2 ? -INFINITY : z2;
+            const float z_top = min3_f32(z0, u1, u2);
+            const float z_bot = max3_f32(z3, l1, l2);
+            const float dz = z_top - z_bot;  // line.cpp:124-131
+            if (dz > 0.0f && dz < INFINITY) {
+                ++n_seg;
+                tau = fma(static_cast<double>(dz), static_cast<double>(o.x), tau);  // line.cpp:189 (unclamped alpha)
+                pend = true;
+                pend_dz = dz;
+                pend_opt = o;
+            }
+            uint32_t w_out;
+            float z_exit;
+            if (kUp) {  // leaves through the lowest upper face: ids of slots 0, 1, 2
+                w_out = (z0 == z_top) ? gw.x : (u1 == z_top) ? gw.y : gw.z;
+                z_exit = z_top;
+            } else {    // through the highest lower face: ids of slots 1, 2, 3
+                w_out = (z3 == z_bot) ? gw.z : (l2 == z_bot) ? gw.y : gw.x;
+                z_exit = z_bot;
+            }
+            const uint32_t id = w_out & kIdMask;
+            int nxt = static_cast<int>(id);
+            if (id == kNoCell) {  // left the grid: re-entry of a non-convex grid?
+                const size_t lp = pixel_index();
+                double s_cur = my_scur[lane];
+                if (fabsf(z_exit) < INFINITY) {
+                    const double z_abs = static_cast<double>(P.z0[nb]) + static_cast<double>(z_exit);
+                    s_cur = fmin(s_cur, kUp ? -z_abs : z_abs);
+                }
+                nxt = next_entry<kUp>(P, lp, load_entry_head(P.entry_head + lp), s_cur);
+                my_scur[lane] = s_cur;
+            }
+            nb = nxt;
+        }
+    }
+    if (pend) {  // the last step's contribution
+        const float xarg = -(pend_opt.y * pend_dz);
+        const double em1 = (xarg > -0.125f) ? static_cast<double>(expm1_small(xarg)) : exp_nonpositive(static_cast<double>(xarg)) - 1.0;
+        const double S = static_cast<double>(pend_opt.z);
+        if (ORDER == 0) {
+            I = fma(I - S, em1, I);
+        } else if (T >= P.t_cutoff) {
+            I = fma(-(T * S), em1, I);
+            T = fma(T, em1, T);
+        }
+    }
+
+    const unsigned overflow = n_seg >> 31;
+    n_seg &= ~kOverflowBit;
+    unsigned is_solid = 0, n_entries = 0;
+    if (in_image) {
+        const size_t lp = pixel_index();
+        float2 result = make_float2(static_cast<float>(tau), static_cast<float>(I));  // plane.cpp:165-166
+        const uint32_t mv = P.mask ? P.mask[lp] : 0u;
+        if (mv) {
+            double colour = 0.0;
+            for (int s = 0; s < P.solids.n_slots; ++s)
+                if (mv == static_cast<uint32_t>(s) + 1u) colour = P.solids.colour[s];
+            result.x = static_cast<float>(colour);
+            result.y = result.x;
+            is_solid = 1;
+        }
+        n_entries = static_cast<unsigned>(load_entry_head(P.entry_head + lp).count);
+        if (n_entries) __builtin_nontemporal_store(0ll, reinterpret_cast<long long*>(P.entry_head + lp));
+        __builtin_nontemporal_store(result.x, &P.out[lp].x);
+        __builtin_nontemporal_store(result.y, &P.out[lp].y);
+    }
+
+    if (P.row_cost) {
+        unsigned rs = n_seg;
+#pragma unroll
+        for (int d = TS::WW / 2; d >= 1; d >>= 1) rs += __shfl_xor(rs, d);
+        if ((lane % TS::WW) == 0 && rs && lrow < im.n_local_rows) atomicAdd(P.row_cost + lrow, rs);
+    }
+    const unsigned s_seg = wave_sum_u32(n_seg);
+    const unsigned s_cov = wave_sum_u32(n_seg > 0 ? 1u : 0u);
+    const unsigned s_sol = wave_sum_u32(is_solid);
+    const unsigned s_ovf = wave_sum_u32(overflow);
+    const unsigned s_ent = wave_sum_u32(n_entries);
+    if (lane == 0) {
+        FrameCounters* const fc = P.counters + ((blockIdx.x * 4u + static_cast<unsigned>(wave)) % kCounterShards);
+        if (s_ent) atomicAdd(&fc->entries, static_cast<unsigned long long>(s_ent));
+        if (s_seg) atomicAdd(&fc->segments, static_cast<unsigned long long>(s_seg));
+        if (n_step_wave) atomicAdd(&fc->steps, static_cast<unsigned long long>(n_step_wave));
+        if (s_cov) atomicAdd(&fc->covered, static_cast<unsigned long long>(s_cov));
+        if (s_sol) atomicAdd(&fc->solid_pixels, static_cast<unsigned long long>(s_sol));
+        if (s_ovf) {
+            atomicAdd(&fc->walk_overflow, s_ovf);
+            atomicAdd(P.sticky + 1, s_ovf);
+        }
+    }
+}
+
+template <int TILE, int ORDER>
+static void launch_mixed_t(hipStream_t s, const WalkParams& p) {
+    using TS = TileShape<TILE>;
+    constexpr int TW = TS::WW * TS::GX, TH = TS::WH * TS::GY;
+    const int tiles_x = (p.im.res_x + TW - 1) / TW;
+    const int tiles_y = (p.im.n_local_rows + TH - 1) / TH;
+    if (tiles_x <= 0 || tiles_y <= 0) return;
+    WalkParams q = p;
+    long long blocks;
+    if (p.xcd_mode == 0) {
+        blocks = static_cast<long long>(tiles_x) * tiles_y;
+    } else {
+        const int sb_rows = p.band_rows > 0 ? p.band_rows : 32;
+        const int S = sb_rows / TH > 0 ? sb_rows / TH : 1;
+        const long long n_sb = static_cast<long long>((tiles_x + S - 1) / S) * ((tiles_y + S - 1) / S);
+        blocks = 8ll * ((n_sb + 7) / 8) * S * S;
+        q.band_tiles = S;
+    }
+    hipLaunchKernelGGL((walk_composite_mixed<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256),
+                       static_cast<size_t>(p.lds_pad), s, q);
+}
+
+void launch_walk_mixed(hipStream_t s, const WalkParams& p, int tile_shape) {
+    if (p.order == 0) {
+        switch (tile_shape) {
+            case 1: launch_mixed_t<1, 0>(s, p); break;
+            case 2: launch_mixed_t<2, 0>(s, p); break;
+            default: launch_mixed_t<0, 0>(s, p); break;
+        }
+    } else {
+        switch (tile_shape) {
+            case 1: launch_mixed_t<1, 1>(s, p); break;
+            case 2: launch_mixed_t<2, 1>(s, p); break;
+            default: launch_mixed_t<0, 1>(s, p); break;
+        }
+    }
+}
+
+}  // namespace c5

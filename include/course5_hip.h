@@ -149,6 +149,12 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  once the transmittance T falls below "transmittance_cutoff" (default 1e-12,
  *                  0 disables).  Both agree to rounding wherever the reference's recurrence is
  *                  well conditioned (it is not for DBL_EPSILON <= alpha < ~1e-8).
+ *   "precision"    0 (default): the fp64 walk — images equal the reference's to the last bit of their fp32
+ *                  values, segment counts equal plane::count_all_intersections.  1: fp32 face planes about a
+ *                  cell-local origin on the pixel lattice (64-byte records), fp32 series for exp(-alpha dz) - 1,
+ *                  fp64 only for the tau and I accumulators: within the 1e-5 bar (about 1e-6 in practice), a
+ *                  quarter faster; not bit-faithful, and a ray within ~1e-9 of a projected edge may count a
+ *                  sliver more or less than the reference.
  *   "algorithm"    0 (default for conforming grids): face-adjacency walk.  1: bin_sort_resolve, the
  *                  reference's own algorithm on the GPU (every face of every cell scan-converted onto
  *                  the pixels, per-pixel sort by z, integrate) — handles tet soups, overlapping and

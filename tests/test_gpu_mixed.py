@@ -1,0 +1,158 @@
+"""Option "precision" 1 (walk_mixed.hip): fp32 face planes about a cell-local origin on the pixel lattice,
+fp32 series for exp(-alpha dz) - 1, fp64 accumulators.  Gate: the SAME 1e-5 bar as the fp64 walk
+(tests/parity.py) on every golden vector, on fresh scenes against the oracle, on the non-convex ball, on
+entry chains, with solids, sharded, and on the full C3 frame.  What it may differ in: the last bits of the
+fp32 output and, by a few rays grazing a projected edge within ~1e-9, the segment count."""
+import os
+
+import numpy as np
+import pytest
+
+from course5_amd import capi, meshgen as mg, sharding
+from parity import assert_images_match, compare, golden_fixtures, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _mixed(gpu_ctx):
+    for k in range(8):
+        gpu_ctx.set_solid(k, np.zeros((0, 12)))
+    for name, v in (("tile", 2), ("integration", 0), ("lds_stage", 1), ("algorithm", 0), ("xcd_mode", 2), ("precision", 1)):
+        gpu_ctx.set_option(name, v)
+    gpu_ctx.set_row_range(0, -1)
+    gpu_ctx.set_row_tiles(0, 0, 1)
+    yield
+    gpu_ctx.set_option("precision", 0)
+    gpu_ctx.set_option("integration", 0)
+    gpu_ctx.set_option("tile", 2)
+
+
+def _render(ctx, rots, rx, ry, bounds=mg.REFERENCE_BOUNDS, alpha_limit=2.5):
+    ctx.set_image(rx, ry, bounds)
+    ctx.set_view(rots)
+    ctx.set_alpha_limit(alpha_limit)
+    return ctx.render(), ctx.stats()
+
+
+def _close(a, b, rel=2e-4):
+    return abs(a - b) <= max(3, rel * max(a, b))
+
+
+@pytest.mark.parametrize("integration", [0, 1], ids=["reference-order", "front-to-back"])
+@pytest.mark.parametrize("path", golden_fixtures(), ids=lambda p: os.path.basename(p)[:-4])
+def test_golden_vectors_mixed(gpu_ctx, path, integration):
+    fx = load_golden(path)
+    if fx["name"].startswith("g4_"):
+        pytest.skip("g4 pins the reference's own cancellation noise for alpha in [DBL_EPSILON, 1e-8): only the fp64 "
+                    "walk in reference order reproduces that (DESIGN.md section 5)")
+    gpu_ctx.set_option("integration", integration)
+    rx, ry = (int(v) for v in fx["res"])
+    stride = int(fx["stride"])
+    gpu_ctx.upload_grid(fx["xyz"], fx["cells"], fx["alpha"], fx["q"])
+    for k in range(len(fx["views"])):
+        for tile in (0, 1, 2):
+            gpu_ctx.set_option("tile", tile)
+            img, st = _render(gpu_ctx, fx[f"rots{k}"], rx, ry, fx["bounds"], float(fx["alpha_limit"]))
+            r = assert_images_match(img[::stride, ::stride], fx[f"image{k}"], f"{fx['name']} view {k} tile {tile}")
+            assert r["max_rel"] < 3e-6, r
+            assert _close(st["segments"], int(fx[f"segments{k}"])) and _close(st["covered_pixels"], int(fx[f"covered{k}"]))
+            assert st["walk_overflow"] == 0
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_scenes_mixed_vs_oracle(gpu_ctx, oracle_port, seed):
+    rng = np.random.default_rng(300 + seed)
+    n = int(rng.integers(2, 12))
+    xyz, cells = mg.kuhn_box(n, jitter=0.12, seed=seed)
+    alpha = rng.uniform(0, 5, len(cells))
+    alpha[rng.random(len(cells)) < 0.05] = 0.0       # cells that neither absorb nor emit (line.cpp:220)
+    alpha[rng.random(len(cells)) < 0.03] *= 40.0     # and opaque ones: |alpha dz| > 1/8 takes the general exp
+    q = rng.uniform(0, 2, len(cells))
+    rots = mg.view_rotations(rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-1, 1))
+    limit = float(rng.uniform(1, 200))
+    rx, ry = int(rng.integers(50, 700)), int(rng.integers(40, 500))
+    gpu_ctx.set_option("tile", seed % 3)
+    gpu_ctx.set_option("integration", seed % 2)
+    gpu_ctx.upload_grid(xyz, cells, alpha, q)
+    img, st = _render(gpu_ctx, rots, rx, ry, alpha_limit=limit)
+    ref = oracle_port.render(xyz, cells, alpha, q, rots, rx, ry, mg.REFERENCE_BOUNDS, alpha_limit=limit, threads=8)
+    assert_images_match(img, ref["image"], f"seed {seed}")
+    assert _close(st["segments"], ref["segments"]) and _close(st["covered_pixels"], ref["covered"])
+
+
+@pytest.mark.parametrize("view", [(0.1, 0.07), (0.5, 0.25), (1.3, -0.4)])
+def test_c2_ball_reentry_mixed(gpu_ctx, oracle_port, view):
+    xyz, cells, alpha, q = mg.workload("c2")
+    rots = mg.view_rotations(*view)
+    gpu_ctx.upload_grid(xyz, cells, alpha, q)
+    img, st = _render(gpu_ctx, rots, 400, 300)
+    ref = oracle_port.render(xyz, cells, alpha, q, rots, 400, 300, mg.REFERENCE_BOUNDS, threads=8)
+    assert_images_match(img, ref["image"], f"c2 {view}")
+    assert _close(st["segments"], ref["segments"]) and st["entries"] > st["covered_pixels"]
+    # sharded renders use the same records (the lattice origin is global): bit-equal to the full frame
+    strips = []
+    for rank in range(3):
+        gpu_ctx.set_row_tiles(16, rank, 3)
+        strips.append(gpu_ctx.render())
+    gpu_ctx.set_row_tiles(0, 0, 1)
+    assert np.array_equal(sharding.assemble(strips, 300, 16, 3).view(np.uint32), img.view(np.uint32))
+
+
+@pytest.mark.parametrize("integration", [0, 1], ids=["reference-order", "front-to-back"])
+def test_entry_chains_mixed(gpu_ctx, oracle_port, integration):
+    from test_gpu_parity import _stacked_slabs
+    xyz, cells, alpha, q = _stacked_slabs()
+    gpu_ctx.set_option("integration", integration)
+    gpu_ctx.upload_grid(xyz, cells, alpha, q)
+    for view in ((0.0, 0.0), (0.04, 0.03), (1.0, 0.02)):
+        rots = mg.view_rotations(*view)
+        img, st = _render(gpu_ctx, rots, 300, 220)
+        ref = oracle_port.render(xyz, cells, alpha, q, rots, 300, 220, mg.REFERENCE_BOUNDS, threads=8)
+        assert_images_match(img, ref["image"], f"slabs {view}")
+        assert _close(st["segments"], ref["segments"]) and st["entries"] >= 3 * st["covered_pixels"] > 0
+
+
+def test_solids_and_tiny_cells_mixed(gpu_ctx, oracle_port):
+    xyz, cells, alpha, q = mg.workload("g2")
+    rots = mg.view_rotations(0.1, 0.07)
+    sx, sc = mg.kuhn_box(2, lo=(0.9, -0.2, -0.2), size=0.3)
+    gpu_ctx.set_solid(0, sx[sc], float("nan"))
+    gpu_ctx.set_solid_view(0, rots)
+    gpu_ctx.upload_grid(xyz, cells, alpha, q)
+    img, st = _render(gpu_ctx, rots, 320, 240)
+    t0 = oracle_port.rotate_points(sx, rots)[sc].reshape(-1, 12)
+    ref = oracle_port.render(xyz, cells, alpha, q, rots, 320, 240, mg.REFERENCE_BOUNDS, solid_tets=t0,
+                             solid_colour=np.full(len(t0), np.nan))
+    assert np.array_equal(np.isnan(img), np.isnan(ref["image"])) and st["solid_pixels"] == ref["marked"] > 0
+    assert_images_match(img, ref["image"], "solids")
+    gpu_ctx.set_solid(0, np.zeros((0, 12)))
+    # cells far smaller than a pixel, far from the lattice origin's neighbours: every lane in its own cell
+    xyz, cells = mg.kuhn_box(14, lo=(1.0, 0.1, -0.05), size=0.02, jitter=0.1, seed=8)
+    alpha, q = mg.scalars(len(cells), seed=8)
+    gpu_ctx.upload_grid(xyz, cells, 50 * alpha, q)
+    img, st = _render(gpu_ctx, mg.view_rotations(0.3, -0.2), 640, 480)
+    ref = oracle_port.render(xyz, cells, 50 * alpha, q, mg.view_rotations(0.3, -0.2), 640, 480, mg.REFERENCE_BOUNDS, threads=8)
+    assert ref["covered"] > 10
+    assert_images_match(img, ref["image"], "sub-pixel cells")
+
+
+def test_c3_full_frame_mixed_against_the_cpu_oracle(gpu_ctx, oracle_port):
+    xyz, cells, alpha, q = mg.workload("c3")
+    rots = mg.view_rotations(**mg.BENCH_VIEW)
+    gpu_ctx.upload_grid(xyz, cells, alpha, q)
+    img, st = _render(gpu_ctx, rots, 2400, 1800)
+    ref = oracle_port.render(xyz, cells, alpha, q, rots, 2400, 1800, mg.REFERENCE_BOUNDS, threads=16)
+    r = assert_images_match(img, ref["image"], "C3 at 2400x1800, mixed precision, vs the oracle")
+    assert r["max_rel"] < 3e-6, r
+    assert abs(st["segments"] - ref["segments"]) <= 2000 and abs(st["covered_pixels"] - ref["covered"]) <= 20
+    print(f"mixed C3: max rel {r['max_rel']:.2e}, segments {st['segments'] - ref['segments']:+d}, "
+          f"covered {st['covered_pixels'] - ref['covered']:+d}, fp32 values that differ {r['differing']} of {img.size}")
+    # against the fp64 walk too, and front-to-back
+    gpu_ctx.set_option("precision", 0)
+    exact, _ = _render(gpu_ctx, rots, 2400, 1800)
+    gpu_ctx.set_option("precision", 1)
+    assert compare(img, exact)["outliers"] == 0
+    gpu_ctx.set_option("integration", 1)
+    ftb, _ = _render(gpu_ctx, rots, 2400, 1800)
+    assert compare(ftb, exact)["outliers"] == 0
