@@ -76,6 +76,7 @@ def parse():
     p.add_argument("--backend", default="nccl", help="nccl (= RCCL, default); gloo only to rehearse N > 1 on one GPU")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-host-image", action="store_true", help="skip the second figure: frames delivered to host memory")
+    p.add_argument("--no-mixed", action="store_true", help="skip the second figure with option \"precision\" 1")
     p.add_argument("--no-native", action="store_true", help="skip the figures of the C++ host (`course --bench`)")
     p.add_argument("--no-steady", action="store_true", help="skip the clock-steadying frames after the W warm-up steps (profiling passes)")
     p.add_argument("--cpu-sample-res", default="", help="image size of the CPU baseline (default: the benchmark's own)")
@@ -365,6 +366,36 @@ def main():
     if world == 1 and not args.no_host_image and hasattr(ctx, "render_host_async"):
         host_image = ctx.bench_host_frames(min(args.steps, 100))
 
+    # Second figure: the same frames with option "precision" 1 (fp32 face planes about a cell-local lattice origin,
+    # fp64 accumulators; every parity test of tests/test_gpu_mixed.py holds the 1e-5 bar).  Never the headline:
+    # the reference computes in fp64 and so does `value`.
+    mixed = None
+    if world == 1 and args.precision < 0 and not args.no_mixed:
+        with torch.cuda.stream(stream):
+            ctx.set_option("precision", 1)
+            strip = torch.zeros((res_y, res_x, 2), dtype=torch.float32, device=dev)
+            for _ in range(60):
+                render(strip)
+            ctx.synchronize()
+            ctx.walk_kernel_ms(reset=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                render(strip)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            rc = ctx.synchronize()
+            wm, _ = ctx.walk_kernel_ms(reset=True)
+            st_m = ctx.stats()
+            ctx.set_option("precision", 0)
+            mixed = {"value": round(res_x * res_y * args.steps / dt / 1e6, 2), "unit": "Mrays/s",
+                     "ms_per_step": round(dt * 1e3 / args.steps, 4), "kernel_ms": round(wm, 4), "status": rc,
+                     "segments_per_frame": st_m["segments"],
+                     "what": "option \"precision\" 1: fp32 face planes about a cell-local origin on the pixel lattice "
+                             "(64-byte records), fp32 series for exp(-alpha dz) - 1, fp64 tau / I accumulators, cells with "
+                             "a face steep against the rays evaluated in fp64 (scalar loads); within the 1e-5 bar on every "
+                             "parity test, not bit-faithful"}
+
     # The C++ host on the same workload: rank 0 runs it as a child process on all N GPUs while the other ranks
     # idle at the barrier below (their GPUs are free: nothing of this job is running on them).
     native = None
@@ -466,6 +497,8 @@ def main():
         }
         if host_image is not None:
             out["value_host_image"] = host_image
+        if mixed is not None:
+            out["value_mixed_precision"] = mixed
         if native is not None:
             out["native_host"] = {"what": "the C++ host `course --bench` (one process, one c5_context per GPU) on the same grid, "
                                           "view and image; frames delivered to pinned host memory; Mrays/s in mrays_per_s",

@@ -124,6 +124,7 @@ struct c5_context {
     int lds_pad = 0;
     int band_rows = 0;
     int order = 0;
+    double steep_ratio = 128.0;  // "precision" 1: cells whose fp32 plane terms exceed this many cell extents are evaluated in fp64
     int precision = 0;  // 0: fp64 walk, bit-faithful (default); 1: fp32 geometry + fp64 accumulators (walk_mixed.hip)
     int lds_stage = 1;
     int stage_timing = 1;
@@ -419,7 +420,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
         g.geo = fs.geo.as<c5::GeoRecord>();
         g.opt32 = fs.opt32.as<c5::OptRecord>();
         g.z0 = fs.z0.as<float>();
-        c5::launch_build_records_mixed(s, g, im, ctx->xtab.as<double>(), ctx->ytab.as<double>(), ctx->alpha_limit, ctx->order);
+        c5::launch_build_records_mixed(s, g, im, ctx->xtab.as<double>(), ctx->ytab.as<double>(), ctx->alpha_limit, ctx->order, ctx->steep_ratio);
     } else {
         c5::launch_build_records(s, g, ctx->alpha_limit, ctx->order);
     }
@@ -1058,6 +1059,9 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
         ctx->lds_stage = static_cast<int>(value) != 0;
     } else if (n == "integration") {
         ctx->order = static_cast<int>(value) != 0;
+    } else if (n == "steep_ratio") {
+        if (!(value >= 0.0)) return fail(ctx, C5_ERR_INVALID, "steep_ratio must be >= 0 (0: never fall back to fp64)");
+        ctx->steep_ratio = value;
     } else if (n == "precision") {
         if (value != 0 && value != 1) return fail(ctx, C5_ERR_INVALID, "precision must be 0 (fp64) or 1 (mixed)");
         ctx->precision = static_cast<int>(value);

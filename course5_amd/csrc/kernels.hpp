@@ -89,7 +89,7 @@ void launch_walk(hipStream_t s, const WalkParams& p, int tile_shape);
 
 // walk_mixed.hip ("precision" 1)
 void launch_build_records_mixed(hipStream_t s, const GridView& g, const ImageParams& im, const double* Xtab,
-                                const double* Ytab, double alpha_limit, int order);
+                                const double* Ytab, double alpha_limit, int order, double steep_ratio);
 void launch_walk_mixed(hipStream_t s, const WalkParams& p, int tile_shape);
 bool mixed_precision_fits(int64_t n_cells, const ImageParams& im);
 

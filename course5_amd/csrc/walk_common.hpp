@@ -45,15 +45,16 @@ __device__ __forceinline__ FacePlane face_plane(const double (&p)[4][3], int f) 
 }
 
 __device__ __forceinline__ bool build_cell_impl(const GridView& g, double alpha_limit, int order, int64_t cell,
-                                                CellRecord& r, CellOptics& o);
+                                                CellRecord& r, CellOptics& o, double (*verts)[3]);
+// verts (optional): the cell's four transformed vertices
 __device__ __forceinline__ bool build_cell(const GridView& g, double alpha_limit, int order, int64_t cell, CellRecord& r,
-                                           CellOptics& o) {
-    return build_cell_impl(g, alpha_limit, order, cell, r, o);
+                                           CellOptics& o, double (*verts)[3] = nullptr) {
+    return build_cell_impl(g, alpha_limit, order, cell, r, o, verts);
 }
 
 // Records of one cell; false if the cell is outside this context's row band (nothing to store).
 __device__ __forceinline__ bool build_cell_impl(const GridView& g, double alpha_limit, int order, int64_t cell,
-                                                CellRecord& r, CellOptics& o) {
+                                                CellRecord& r, CellOptics& o, double (*verts)[3]) {
     const int4 cv = g.cell_vert[cell];
     const int vid[4] = {cv.x, cv.y, cv.z, cv.w};
     double p[4][3];
@@ -72,6 +73,14 @@ __device__ __forceinline__ bool build_cell_impl(const GridView& g, double alpha_
         p[k][2] = g.vz[vid[k]];
     }
 
+    if (verts) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            verts[k][0] = p[k][0];
+            verts[k][1] = p[k][1];
+            verts[k][2] = p[k][2];
+        }
+    }
     FacePlane fp[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) fp[f] = face_plane(p, f);

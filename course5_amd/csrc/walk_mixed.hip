@@ -34,6 +34,8 @@ bool mixed_precision_fits(int64_t n_cells, const ImageParams& im) {
 // build_records_mixed: one thread per cell.  The planes are the fp64 ones of build_records (same
 // classification, same walk order, same neighbour words), re-expressed about the lattice origin and narrowed.
 // ------------------------------------------------------------------------------------------
+constexpr uint32_t kExactBit = 1u << 29;  // GeoRecord::w[0]: evaluate this cell from its fp64 CellRecord
+
 struct alignas(16) F4 {
     float a, b, c, d;
 };
@@ -42,24 +44,28 @@ struct alignas(16) U4 {
 };
 
 __global__ __launch_bounds__(256) void build_records_mixed(GridView g, ImageParams im, const double* __restrict__ Xtab,
-                                                           const double* __restrict__ Ytab, double alpha_limit, int order) {
+                                                           const double* __restrict__ Ytab, double alpha_limit, int order,
+                                                           double steep_ratio) {
     const int64_t cell = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
     if (cell >= g.n_cells) return;
     CellRecord r;
     CellOptics o;
-    if (!build_cell(g, alpha_limit, order, cell, r, o)) return;  // outside this context's row band
+    double v[4][3];
+    if (!build_cell(g, alpha_limit, order, cell, r, o, v)) return;  // outside this context's row band
 
-    // origin: the pixel nearest (x0, y0), clamped to the image (a cell outside the domain is never walked)
-    const double fc = rint((r.x0 - im.x_min) / im.step_x), fr = rint((r.y0 - im.y_min) / im.step_y);
+    // origin: the pixel nearest the centre of the cell's footprint, clamped to the image (a cell outside the
+    // domain is never walked)
+    const double cx = 0.25 * (v[0][0] + v[1][0] + v[2][0] + v[3][0]), cy = 0.25 * (v[0][1] + v[1][1] + v[2][1] + v[3][1]);
+    const double fc = rint((cx - im.x_min) / im.step_x), fr = rint((cy - im.y_min) / im.step_y);
     const int col0 = static_cast<int>(fmin(fmax(fc, 0.0), im.res_x - 1.0));
     const int row0 = static_cast<int>(fmin(fmax(fr, 0.0), im.res_y - 1.0));
-    const double ox = Xtab[col0] - r.x0, oy = Ytab[row0] - r.y0;
+    const double Xc = Xtab[col0], Yr = Ytab[row0];
+    const double ox = Xc - r.x0, oy = Yr - r.y0;
     double c0[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) c0[k] = fma(r.plane[k][1], ox, fma(r.plane[k][2], oy, r.plane[k][0]));  // depth of plane k at the origin
-    // depth origin: a finite plane's depth at the lattice origin (slot 0 is an upper face unless the cell is flat)
-    const double zref = (fabs(c0[0]) <= DBL_MAX) ? c0[0] : ((fabs(c0[3]) <= DBL_MAX) ? c0[3] : 0.0);
-    const float z0f = static_cast<float>(zref);
+    // depth origin: vertex 0 (NOT a plane's depth at the lattice origin: a steep face is far from the cell there)
+    const float z0f = static_cast<float>(v[0][2]);
     GeoRecord out;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -67,9 +73,32 @@ __global__ __launch_bounds__(256) void build_records_mixed(GridView g, ImagePara
         out.plane[k][1] = static_cast<float>(r.plane[k][1] * im.step_x);
         out.plane[k][2] = static_cast<float>(r.plane[k][2] * im.step_y);
     }
+    // Is single precision enough for this cell?  fp32 evaluates plane k at a pixel with an absolute error of
+    // about 1e-7 (|c'| + |gx' dcol| + |gy' drow|): harmless while those terms are of the size of the cell, but a
+    // face that is steep against the rays makes them large and cancelling.  Bound them over the cell's own
+    // footprint (they are largest at one of its vertices) and compare with the cell's extent along the rays:
+    // beyond steep_ratio (option "steep_ratio") the cell is marked and the walk evaluates it from its fp64 record instead.
+    double worst = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!(fabs(c0[k]) <= DBL_MAX)) continue;  // edge-on / flat slot: +-inf, exact
+        const double cabs = fabs(c0[k] - static_cast<double>(z0f));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            worst = fmax(worst, cabs + fabs(r.plane[k][1] * (v[j][0] - Xc)) + fabs(r.plane[k][2] * (v[j][1] - Yr)));
+    }
+    const double z_lo = fmin(fmin(v[0][2], v[1][2]), fmin(v[2][2], v[3][2]));
+    const double z_hi = fmax(fmax(v[0][2], v[1][2]), fmax(v[2][2], v[3][2]));
+    const bool steep = steep_ratio > 0.0 && !(worst <= steep_ratio * (z_hi - z_lo));  // (NaN -> steep)
+    if (steep) {
+        const U4* rs = reinterpret_cast<const U4*>(&r);
+        U4* rd = reinterpret_cast<U4*>(g.rec + cell);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rd[k] = rs[k];
+    }
     const uint32_t n_up = r.nbr[0] >> kUpperCountShift;
     const int first = (order == 0) ? 0 : 1;  // exit candidates: slots 0..2 walking up, 1..3 walking down
-    out.w[0] = (r.nbr[first] & kIdMask) | (n_up << kUpperCountShift);
+    out.w[0] = (r.nbr[first] & kIdMask) | (n_up << kUpperCountShift) | (steep ? kExactBit : 0u);
     out.w[1] = r.nbr[first + 1] & kIdMask;
     out.w[2] = r.nbr[first + 2] & kIdMask;
     out.w[3] = static_cast<uint32_t>(col0) | (static_cast<uint32_t>(row0) << 16);
@@ -88,10 +117,10 @@ __global__ __launch_bounds__(256) void build_records_mixed(GridView g, ImagePara
 }
 
 void launch_build_records_mixed(hipStream_t s, const GridView& g, const ImageParams& im, const double* Xtab,
-                                const double* Ytab, double alpha_limit, int order) {
+                                const double* Ytab, double alpha_limit, int order, double steep_ratio) {
     if (g.n_cells <= 0) return;
     const unsigned blocks = static_cast<unsigned>((g.n_cells + 255) / 256);
-    hipLaunchKernelGGL(build_records_mixed, dim3(blocks), dim3(256), 0, s, g, im, Xtab, Ytab, alpha_limit, order);
+    hipLaunchKernelGGL(build_records_mixed, dim3(blocks), dim3(256), 0, s, g, im, Xtab, Ytab, alpha_limit, order, steep_ratio);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -103,6 +132,7 @@ constexpr int kMixStride = 5;        // 16-byte units per slot: 4 of GeoRecord +
 constexpr unsigned kMixBuckets = 256;
 
 using V4F = float __attribute__((ext_vector_type(4)));
+using SRec16 = int __attribute__((ext_vector_type(16)));  // half a CellRecord in scalar registers
 using V4U = uint32_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float min3_f32(float a, float b, float c) {
@@ -127,8 +157,37 @@ __device__ __forceinline__ float expm1_small(float x) {
     return p * x;
 }
 
+// exp(x) for x <= 0, the general case (|alpha dz| >= 1/8: rare in this kernel).  exp_nonpositive keeps its
+// coefficients in scalar registers for the whole loop — twenty SGPRs, which here would cost a wavefront per SIMD —
+// so this copy materialises each constant where it is used (the empty asm keeps it from being hoisted).
+__device__ __forceinline__ double exp_nonpositive_local(double x) {
+#pragma clang fp contract(fast)
+    auto local = [](double c) {
+        asm volatile("" : "+s"(c));
+        return c;
+    };
+    x = fmax(x, local(-746.0));
+    const double k = rint(x * local(1.4426950408889634074));
+    double r = fma(k, local(-6.93147180369123816490e-01), x);
+    r = fma(k, local(-1.90821492927058770002e-10), r);
+    double p = fma(local(1.0 / 6227020800.0), r, local(1.0 / 479001600.0));
+    p = fma(p, r, local(1.0 / 39916800.0));
+    p = fma(p, r, local(1.0 / 3628800.0));
+    p = fma(p, r, local(1.0 / 362880.0));
+    p = fma(p, r, local(1.0 / 40320.0));
+    p = fma(p, r, local(1.0 / 5040.0));
+    p = fma(p, r, local(1.0 / 720.0));
+    p = fma(p, r, local(1.0 / 120.0));
+    p = fma(p, r, local(1.0 / 24.0));
+    p = fma(p, r, local(1.0 / 6.0));
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, static_cast<int>(k));
+}
+
 template <int TILE, int ORDER>
-__global__ __launch_bounds__(256, 6) void walk_composite_mixed(WalkParams P) {
+__global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(80))) void walk_composite_mixed(WalkParams P) {
     using TS = TileShape<TILE>;
     constexpr int TW = TS::WW * TS::GX, TH = TS::WH * TS::GY;
     constexpr bool kUp = (ORDER == 0);
@@ -279,7 +338,7 @@ __global__ __launch_bounds__(256, 6) void walk_composite_mixed(WalkParams P) {
                     }
                 }
             } else if (pend) {
-                const double e = exp_nonpositive(static_cast<double>(xarg));
+                const double e = exp_nonpositive_local(static_cast<double>(xarg));
                 const double S = static_cast<double>(pend_opt.z);
                 if (ORDER == 0) {
                     if (pend_opt.y != 0.0f) I = fma(I - S, e - 1.0, I);
@@ -299,24 +358,26 @@ __global__ __launch_bounds__(256, 6) void walk_composite_mixed(WalkParams P) {
 
         // 4. every ray fetches its cell
         if (need) {
-            V4F g0, g1, g2, o;
-            V4U gw;
-            if (slot < kMixSlots) {
-                const V4F* r = reinterpret_cast<const V4F*>(reinterpret_cast<const char*>(my_stage) +
-                                                            __umul24(static_cast<unsigned>(slot), kMixStride * 16u));
-                g0 = r[0];
-                g1 = r[1];
-                g2 = r[2];
-                gw = *reinterpret_cast<const V4U*>(r + 3);
-                o = r[4];
-            } else {  // more distinct cells than slots: rare in 8x8 tiles
-                const V4F* r = reinterpret_cast<const V4F*>(P.geo + nb);
-                g0 = r[0];
-                g1 = r[1];
-                g2 = r[2];
-                gw = *reinterpret_cast<const V4U*>(r + 3);
+            // Five LDS reads, issued together and kept LDS reads: left to itself hipcc merges the staged and
+            // the direct path into flat loads through a generic pointer and defers the optics read into the
+            // "contributes" branch, one more round trip on the critical path.
+            const V4F* r = reinterpret_cast<const V4F*>(reinterpret_cast<const char*>(my_stage) +
+                                                        __umul24(static_cast<unsigned>(slot) & (kMixSlots - 1u), kMixStride * 16u));
+            V4F g0 = r[0], g1 = r[1], g2 = r[2], gwf = r[3], o = r[4];
+            asm volatile("" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(gwf), "+v"(o));
+            if (slot >= kMixSlots) {  // more distinct cells than slots: rare in 8x8 tiles
+                const V4F* gr = reinterpret_cast<const V4F*>(P.geo + nb);
+                g0 = gr[0];
+                g1 = gr[1];
+                g2 = gr[2];
+                gwf = gr[3];
                 o = *reinterpret_cast<const V4F*>(P.opt32 + nb);
             }
+            V4U gw;
+            gw.x = __float_as_uint(gwf.x);
+            gw.y = __float_as_uint(gwf.y);
+            gw.z = __float_as_uint(gwf.z);
+            gw.w = __float_as_uint(gwf.w);
             // planes (c, gx, gy): g0.xyz | g0.w g1.xy | g1.zw g2.x | g2.yzw
             const float dcol = static_cast<float>(col - static_cast<int>(gw.w & 0xFFFFu));
             const float drow = static_cast<float>(grow - static_cast<int>(gw.w >> 16));
@@ -330,15 +391,8 @@ __global__ __launch_bounds__(256, 6) void walk_composite_mixed(WalkParams P) {
             const float u2 = up2 ? z2 : INFINITY, l2 = up2 ? -INFINITY : z2;
             const float z_top = min3_f32(z0, u1, u2);
             const float z_bot = max3_f32(z3, l1, l2);
-            const float dz = z_top - z_bot;  // line.cpp:124-131
-            if (dz > 0.0f && dz < INFINITY) {
-                ++n_seg;
-                tau = fma(static_cast<double>(dz), static_cast<double>(o.x), tau);  // line.cpp:189 (unclamped alpha)
-                pend = true;
-                pend_dz = dz;
-                pend_opt = o;
-            }
-            uint32_t w_out;
+            float dz = z_top - z_bot;  // chord through the cell (line.cpp:124-131)
+            uint32_t w_out;            // neighbour word of the exit face
             float z_exit;
             if (kUp) {  // leaves through the lowest upper face: ids of slots 0, 1, 2
                 w_out = (z0 == z_top) ? gw.x : (u1 == z_top) ? gw.y : gw.z;
@@ -347,12 +401,86 @@ __global__ __launch_bounds__(256, 6) void walk_composite_mixed(WalkParams P) {
                 w_out = (z3 == z_bot) ? gw.z : (l2 == z_bot) ? gw.y : gw.x;
                 z_exit = z_bot;
             }
+            bool has_exit = fabsf(z_exit) < INFINITY;
+            double dz_tau = static_cast<double>(dz);
+
+            // Cells with a face steep against the rays (build_records_mixed: kExactBit; ~2 % of cells): fp32 would
+            // lose the chord in the cancellation, so they are evaluated from their fp64 record.  Per distinct such
+            // cell of the wavefront (usually one) the record is fetched with SCALAR loads — 128 bytes into SGPRs,
+            // no vector registers, so the kernel keeps its 8 wavefronts per SIMD — and the lanes inside that cell
+            // redo the four planes in fp64 with the coefficients as scalar operands.
+            const bool steep = (gw.x & kExactBit) != 0u;
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(steep);
+            while (todo != 0ull) {
+                const int first_lane = __builtin_ctzll(todo);
+                const int id = __builtin_amdgcn_readlane(nb, first_lane);
+                const bool mine = steep && nb == id;
+                todo &= ~__builtin_amdgcn_ballot_w64(mine);
+                const CellRecord* rec = P.rec + id;  // uniform address
+                // two rounds of 64 bytes through the same sixteen scalar registers (the kernel's SGPR count, like its
+                // VGPR count, decides how many wavefronts a SIMD holds)
+                auto dbl = [](int a, int b) { return __hiloint2double(b, a); };
+                double dx = 0.0, dy = 0.0, e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;
+                uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+                if (mine) {
+                    dx = P.Xtab[col];
+                    dy = P.Ytab[grow];
+                }
+                {   // CellRecord bytes 0-63: x0 y0 | plane[0] c gx gy | plane[1] c gx gy
+                    SRec16 h;
+                    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(h) : "s"(rec) : "memory");
+                    if (mine) {
+                        dx -= dbl(h[0], h[1]);
+                        dy -= dbl(h[2], h[3]);
+                        e0 = fma(dbl(h[6], h[7]), dx, fma(dbl(h[8], h[9]), dy, dbl(h[4], h[5])));
+                        e1 = fma(dbl(h[12], h[13]), dx, fma(dbl(h[14], h[15]), dy, dbl(h[10], h[11])));
+                    }
+                }
+                {   // bytes 64-127: plane[2] | plane[3] | nbr[4]
+                    SRec16 h;
+                    asm volatile("s_load_dwordx16 %0, %1, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(h) : "s"(rec) : "memory");
+                    if (mine) {
+                        e2 = fma(dbl(h[2], h[3]), dx, fma(dbl(h[4], h[5]), dy, dbl(h[0], h[1])));
+                        e3 = fma(dbl(h[8], h[9]), dx, fma(dbl(h[10], h[11]), dy, dbl(h[6], h[7])));
+                    }
+                    q0 = static_cast<uint32_t>(h[12]);
+                    q1 = static_cast<uint32_t>(h[13]);
+                    q2 = static_cast<uint32_t>(h[14]);
+                    q3 = static_cast<uint32_t>(h[15]);
+                }
+                if (mine) {
+                    const uint32_t nu = q0 >> kUpperCountShift;  // wave-uniform
+                    const double a1 = nu > 1u ? e1 : INFINITY, b1 = nu > 1u ? -INFINITY : e1;
+                    const double a2 = nu > 2u ? e2 : INFINITY, b2 = nu > 2u ? -INFINITY : e2;
+                    const double zt = fmin(e0, fmin(a1, a2)), zb = fmax(e3, fmax(b1, b2));
+                    dz_tau = zt - zb;
+                    dz = static_cast<float>(dz_tau);
+                    double ze;
+                    if (kUp) {
+                        w_out = (e0 == zt) ? q0 : (a1 == zt) ? q1 : q2;
+                        ze = zt;
+                    } else {
+                        w_out = (e3 == zb) ? q3 : (b2 == zb) ? q2 : q1;
+                        ze = zb;
+                    }
+                    // leaving the grid from here: the exit depth goes to the lane's s_cur now (it is absolute already)
+                    if ((w_out & kIdMask) == kNoCell && fabs(ze) < INFINITY) my_scur[lane] = fmin(my_scur[lane], kUp ? -ze : ze);
+                    has_exit = false;
+                }
+            }
+            if (dz > 0.0f && dz < INFINITY) {
+                ++n_seg;
+                tau = fma(dz_tau, static_cast<double>(o.x), tau);  // line.cpp:189 (unclamped alpha)
+                pend = true;
+                pend_dz = dz;
+                pend_opt = o;
+            }
             const uint32_t id = w_out & kIdMask;
             int nxt = static_cast<int>(id);
             if (id == kNoCell) {  // left the grid: re-entry of a non-convex grid?
                 const size_t lp = pixel_index();
                 double s_cur = my_scur[lane];
-                if (fabsf(z_exit) < INFINITY) {
+                if (has_exit) {
                     const double z_abs = static_cast<double>(P.z0[nb]) + static_cast<double>(z_exit);
                     s_cur = fmin(s_cur, kUp ? -z_abs : z_abs);
                 }
@@ -364,7 +492,7 @@ __global__ __launch_bounds__(256, 6) void walk_composite_mixed(WalkParams P) {
     }
     if (pend) {  // the last step's contribution
         const float xarg = -(pend_opt.y * pend_dz);
-        const double em1 = (xarg > -0.125f) ? static_cast<double>(expm1_small(xarg)) : exp_nonpositive(static_cast<double>(xarg)) - 1.0;
+        const double em1 = (xarg > -0.125f) ? static_cast<double>(expm1_small(xarg)) : exp_nonpositive_local(static_cast<double>(xarg)) - 1.0;
         const double S = static_cast<double>(pend_opt.z);
         if (ORDER == 0) {
             I = fma(I - S, em1, I);
