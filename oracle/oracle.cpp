@@ -247,6 +247,24 @@ void c5o_pixel_coords(int res_x, int res_y, const double* bounds4, double* X, do
     std::memcpy(Y, g.Y.data(), sizeof(double) * g.Y.size());
 }
 
+// One face through the scan conversion (plane.cpp:57-142 as restated in scan.hpp): the covered pixels
+// (col, row) in emission order, for unit tests with hand-computed triangles.  Returns the count (which may
+// exceed cap; only the first cap pairs are stored).
+int64_t c5o_scan_face(int res_x, int res_y, const double* bounds4, const double* v0, const double* v1, const double* v2,
+                      int32_t* out_ij, int64_t cap) {
+    PixelGrid g;
+    g.init(static_cast<size_t>(res_x), static_cast<size_t>(res_y), bounds4);
+    int64_t n = 0;
+    c5scan::scan_face(g, v0, v1, v2, [&](size_t i, size_t j) {
+        if (n < cap) {
+            out_ij[2 * n] = static_cast<int32_t>(i);
+            out_ij[2 * n + 1] = static_cast<int32_t>(j);
+        }
+        ++n;
+    });
+    return n;
+}
+
 // Full render.
 //   xyz[n_pts][3], cell_vert[n_cells][4], alpha[n_cells], q[n_cells]: the volume grid (raw);
 //   rots[n_rot][3]: view rotations applied to every grid vertex copy (main.cpp:105-107);

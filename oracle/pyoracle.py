@@ -71,6 +71,17 @@ class Oracle:
     def emission_step(self, I, alpha, Q, dz, alpha_limit) -> float:
         return self.lib.c5o_emission_step(I, alpha, Q, dz, alpha_limit)
 
+    def scan_face(self, res_x, res_y, bounds, v0, v1, v2, cap=1 << 16):
+        """Pixels (col, row) one projected face covers (plane.cpp:57-142), in emission order ("port" only)."""
+        b = np.ascontiguousarray(bounds, dtype=np.float64)
+        vs = [np.ascontiguousarray(v, dtype=np.float64) for v in (v0, v1, v2)]
+        out = np.zeros((cap, 2), dtype=np.int32)
+        fn = self.lib.c5o_scan_face
+        fn.restype = C.c_int64
+        n = fn(C.c_int(res_x), C.c_int(res_y), _ptr(b, _dp), _ptr(vs[0], _dp), _ptr(vs[1], _dp), _ptr(vs[2], _dp),
+               _ptr(out, _ip), C.c_int64(cap))
+        return out[:min(n, cap)].copy(), int(n)
+
     def pixel_coords(self, res_x, res_y, bounds):
         b = np.ascontiguousarray(bounds, dtype=np.float64)
         X = np.empty(res_x)

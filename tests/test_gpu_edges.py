@@ -160,3 +160,29 @@ def test_volume_grid_across_the_domain_border(gpu_ctx, oracle_port):
         a, c = exact[1:-1, 1:-1].astype(np.float64), walk[1:-1, 1:-1].astype(np.float64)
         bad = np.abs(a - c) > 1e-5 * np.maximum(np.abs(a), np.abs(c)) + 1e-6 * np.abs(c).max()
         assert bad.sum() == 0, (k, int(bad.sum()))
+
+
+def test_solid_raster_on_the_hand_computed_triangles(gpu_ctx):
+    """The device restatement of the coverage rule (exact_kernels.hip: FaceScan, used by solid_mask_raster and
+    bin_cells) against the same expectations as the oracle's (tests/test_scan_face.py): closed triangles by exact
+    rational arithmetic, and the hand-worked clamp smears of plane.cpp:194-212.  A solid "cell" (A, B, C, C) has one
+    real face; its other three are the face again or zero-area segments that cover no pixel centre."""
+    from test_scan_face import BOUNDS, REGULAR, RX, RY, inside_closed
+    far = np.array([[50.0, 50, 50], [51, 50, 50], [50, 51, 50], [50, 50, 51]])
+    gpu_ctx.upload_grid(far, np.array([[0, 1, 2, 3]], dtype=np.int32), np.ones(1), np.ones(1))
+
+    def mask_of(tri):
+        pts = [np.array([x, y, 0.25 * k]) for k, (x, y) in enumerate(tri)]
+        gpu_ctx.set_solid(0, np.array([[pts[0], pts[1], pts[2], pts[2]]]).reshape(1, 12), float("nan"))
+        gpu_ctx.set_solid_view(0, np.zeros((0, 3)))
+        img, _ = _render(gpu_ctx, np.zeros((0, 3)), RX, RY, BOUNDS)
+        rows, cols = np.nonzero(np.isnan(img[..., 0]))
+        return sorted(zip(cols.tolist(), rows.tolist()))
+
+    for name, tri in REGULAR.items():
+        assert mask_of(tri) == inside_closed(tri), name
+    assert mask_of([(7.5, 1.5), (12.5, 1.5), (12.5, 5.5)]) == [(9, 2), (9, 3), (9, 4), (9, 5)]
+    assert mask_of([(10.5, 1.5), (13.0, 2.5), (11.0, 4.5)]) == [(9, 2), (9, 3), (9, 4)]
+    assert mask_of([(-3.5, 2.5), (-1.5, 2.75), (-2.0, 4.25)]) == [(0, 3), (0, 4)]
+    tri = [(2.25, 4.5), (7.75, 4.5), (5.0, 9.5)]
+    assert mask_of(tri) == inside_closed(tri)
