@@ -39,6 +39,7 @@ const option_spec kOptions[] = {
     {"split", 0, true, "several GPUs: rows, frames (frame k of a sweep on GPU k mod N) or auto", "auto"},
     {"bench", 0, true, "render this many sweep frames without writing files and print one JSON line", nullptr},
     {"bench_warmup", 0, true, "untimed frames before --bench", "20"},
+    {"auto_bounds", 0, false, "image domain = bounding box of the transformed objects instead of the fixed domain", nullptr},
     {"no_solids", 0, false, "do not generate the Roche lobe and the accretor sphere", nullptr},
     {"stats", 0, false, "print per-stage GPU timings and segment counts", nullptr},
     {"raw_vti", 0, false, "write the .vti uncompressed (default: zlib blocks, like vtkXMLImageDataWriter)", nullptr},
@@ -127,6 +128,7 @@ bool program_options(int argc, char** argv, std::ostream& out) {
         else if (n == "split") cfg.split = v;
         else if (n == "bench") cfg.bench = static_cast<std::size_t>(std::max(0ll, to_integer(n, v)));
         else if (n == "bench_warmup") cfg.bench_warmup = static_cast<std::size_t>(std::max(0ll, to_integer(n, v)));
+        else if (n == "auto_bounds") cfg.auto_bounds = true;
         else if (n == "no_solids") cfg.no_solids = true;
         else if (n == "stats") cfg.print_stats = true;
         else if (n == "raw_vti") cfg.raw_vti = true;

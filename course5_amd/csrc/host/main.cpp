@@ -51,7 +51,8 @@ int main(int argc, char** argv) try {
         return 0;
     }
 
-    const std::vector<double> domain(DOMAIN_BOUNDS, DOMAIN_BOUNDS + 4);  // main.cpp:83
+    // main.cpp:83; --auto_bounds: empty, so that plane computes the objects' bounding box (plane.cpp:278-288)
+    const std::vector<double> domain = config.auto_bounds ? std::vector<double>{} : std::vector<double>(DOMAIN_BOUNDS, DOMAIN_BOUNDS + 4);
 
     // main.cpp:85-92
     std::cout << "Defined grid resolution: " << config.resolution_x << "x" << config.resolution_y << std::endl;

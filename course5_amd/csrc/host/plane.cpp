@@ -5,6 +5,8 @@
 #include <rccl/rccl.h>  // types and prototypes only: the library is loaded on demand (rccl_api below)
 
 #include <algorithm>
+#include <array>
+#include <cmath>
 #include <cstdio>
 #include <iostream>
 #include <stdexcept>
@@ -144,6 +146,53 @@ struct multi_gpu {
 };
 
 // ------------------------------------------------------------------------------------------------
+// automatic boundaries (plane.cpp:278-288 over object3d_base::get_boundaries, object3d_base.cpp:221-255, over
+// tetra::get_boundaries, tetra.cpp:18-42): the x / y bounding box of every object's TRANSFORMED vertices.  The
+// vertices are transformed on the GPU each frame; for this one-off the host applies the same rotation lists with
+// the reference's arithmetic (tetra.cpp:44-62).  Never used by the reference's own main (main.cpp:83 passes the
+// domain), so this path is not on the hot path either.
+// ------------------------------------------------------------------------------------------------
+std::array<double, 4> bounding_box(std::vector<object3d_base>& objects3d) {
+    bool any = false;
+    double x_max = 0, x_min = 0, y_max = 0, y_min = 0;
+    for (object3d_base& obj : objects3d) {
+        const object3d_data& d = *obj.get_pointer();
+        const std::vector<double>& pts = d.kind == tetra_type::solid ? d.soup : d.points;
+        const std::size_t n = pts.size() / 3;
+        double bx_max = -HUGE_VAL, bx_min = HUGE_VAL, by_max = -HUGE_VAL, by_min = HUGE_VAL;
+#pragma omp parallel for schedule(static) reduction(max : bx_max, by_max) reduction(min : bx_min, by_min)
+        for (std::size_t i = 0; i < n; ++i) {
+            double p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+            for (const c5_rotation& r : d.rotations) {
+                if (r.axis == 0) {  // tetra.cpp:44-48
+                    const double y0 = p[1];
+                    p[1] = p[1] * cos(r.angle) - p[2] * sin(r.angle);
+                    p[2] = y0 * sin(r.angle) + p[2] * cos(r.angle);
+                } else {            // tetra.cpp:51-62
+                    p[0] -= r.x0;
+                    const double xs = p[0];
+                    p[0] = p[0] * cos(r.angle) - p[2] * sin(r.angle);
+                    p[2] = xs * sin(r.angle) + p[2] * cos(r.angle);
+                    p[0] += r.x0;
+                }
+            }
+            bx_max = std::max(bx_max, p[0]);
+            bx_min = std::min(bx_min, p[0]);
+            by_max = std::max(by_max, p[1]);
+            by_min = std::min(by_min, p[1]);
+        }
+        if (n == 0) continue;
+        x_max = any ? std::max(x_max, bx_max) : bx_max;
+        x_min = any ? std::min(x_min, bx_min) : bx_min;
+        y_max = any ? std::max(y_max, by_max) : by_max;
+        y_min = any ? std::min(y_min, by_min) : by_min;
+        any = true;
+    }
+    if (!any) throw std::runtime_error("plane initializer. empty set of objects to render");
+    return {x_max, x_min, y_max, y_min};
+}
+
+// ------------------------------------------------------------------------------------------------
 // plane
 // ------------------------------------------------------------------------------------------------
 void plane::check(int rc, const char* what, std::size_t dev) {
@@ -159,8 +208,10 @@ plane::plane(std::size_t res_x, std::size_t res_y, std::vector<object3d_base> ob
         throw std::runtime_error("plane initializer. wrong manual boundaries");  // plane.cpp:262-264
     if (objects3d.empty())
         throw std::runtime_error("plane initializer. empty set of objects to render");  // plane.cpp:269-271
-    if (global_boundaries.empty())
-        throw std::runtime_error("plane initializer. automatic boundaries are not supported: pass {x_max, x_min, y_max, y_min}");
+    if (global_boundaries.empty()) {
+        const std::array<double, 4> b = bounding_box(objects3d);  // plane.cpp:278-288
+        global_boundaries.assign(b.begin(), b.end());
+    }
     if (_devices.empty()) throw std::runtime_error("plane initializer. no GPU given");
     _x = res_x;
     _y = res_y;

@@ -3,6 +3,7 @@
 // several GPUs of one node (one c5_context and one stream per device, this one process driving them all).
 #pragma once
 
+#include <array>
 #include <cstdint>
 #include <deque>
 #include <memory>
@@ -63,8 +64,8 @@ class plane {
 public:
     plane() = delete;
     // plane.cpp:260-315.  objects3d: volume grids (transparent) and solids, in the reference's order;
-    // global_boundaries = {x_max, x_min, y_max, y_min} (required here: the reference's automatic
-    // bounding box is never used by its own main, main.cpp:83,127).  devices: GPU ordinals, one context
+    // global_boundaries = {x_max, x_min, y_max, y_min}; empty: the bounding box of the transformed objects
+    // (plane.cpp:278-288; the reference's own main always passes the domain, main.cpp:83,127).  devices: GPU ordinals, one context
     // each; with more than one the image rows are dealt to them in cyclic tiles of 16 rows.
     explicit plane(std::size_t res_x, std::size_t res_y, std::vector<object3d_base> objects3d,
                    std::vector<double> global_boundaries = {}, std::vector<int> devices = {0},
@@ -114,6 +115,10 @@ private:
     std::unique_ptr<multi_gpu> _mg;
     std::size_t _retries = 0;
 };
+
+// {x_max, x_min, y_max, y_min} of the objects' transformed vertices: what the reference's plane uses when no
+// boundaries are given (plane.cpp:278-288)
+std::array<double, 4> bounding_box(std::vector<object3d_base>& objects3d);
 
 // "0", "0-7", "0,2,4", "0,0" (the same GPU twice: rehearsal of the multi-GPU path on one GPU)
 std::vector<int> parse_device_list(const std::string& text);

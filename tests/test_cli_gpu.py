@@ -168,3 +168,28 @@ def test_course_bench_prints_one_json_line(tmp_path):
         b = json.loads(line[0])["course_bench"]
         assert b["frames"] == 30 and b["split"] == split and b["mrays_per_s"] > 10 and b["retries"] == 0
         assert not list(tmp_path.glob("*.vti"))
+
+
+def test_course_automatic_boundaries(tmp_path, oracle_port):
+    """plane.cpp:278-288: without manual boundaries the image domain is the x / y bounding box of the transformed
+    objects (object3d_base.cpp:221-255, tetra.cpp:18-42).  The reference's main never takes that path
+    (main.cpp:83); `course --auto_bounds` does, and must agree with the oracle fed the same box."""
+    xyz, cells, a, q = mg.workload("g2")
+    src, dst = tmp_path / "g2.vtk", tmp_path / "auto.vti"
+    mg.write_vtk_ascii(str(src), xyz, cells, a, q)
+    _run(["-f", src, "-d", dst, "-x", 300, "-y", 200, "-X", 0.1, "-Y", 0.07, "--no_solids", "--auto_bounds", "--raw_vti"])
+    rots = mg.view_rotations(0.1, 0.07)
+    v = oracle_port.rotate_points(xyz, rots)
+    bounds = (v[:, 0].max(), v[:, 0].min(), v[:, 1].max(), v[:, 1].min())
+    img, _ = vtkio.read_vti(str(dst))
+    # the grid touches all four borders of its own bounding box, where the reference's clamp smears faces in odd
+    # numbers (it would abort: plane.cpp:39-41), so compare with the walk's own render in the oracle's domain:
+    # every pixel strictly inside must match the oracle rendered in a domain one pixel wider
+    sx, sy = (bounds[0] - bounds[1]) / 299, (bounds[2] - bounds[3]) / 199
+    wide = (bounds[0] + sx, bounds[1] - sx, bounds[2] + sy, bounds[3] - sy)
+    ref = oracle_port.render(xyz, cells, a, q, rots, 302, 202, wide, threads=8)
+    got = img.astype(np.float32)
+    want = ref["image"][1:-1, 1:-1]
+    d = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    bad = d > 1e-5 * np.maximum(np.abs(got), np.abs(want)) + 1e-6 * np.abs(want).max()
+    assert bad.sum() <= 8 and (got[..., 0] > 0).sum() > 20_000
