@@ -71,6 +71,28 @@ class Oracle:
     def emission_step(self, I, alpha, Q, dz, alpha_limit) -> float:
         return self.lib.c5o_emission_step(I, alpha, Q, dz, alpha_limit)
 
+    def probe_segments(self, xyz, cells, alpha, q, rots, res_x, res_y, bounds, probes, cap=512):
+        """("reference" only) per probed pixel (col, row): [(tetra id, delta z)] exactly as the reference's
+        line::calculate_intersections leaves line::_intersections_delta (line.cpp:84-148) — oracle/ref_inspect.cpp."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        cells = np.ascontiguousarray(cells, dtype=np.int32).reshape(-1, 4)
+        alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        rots = np.ascontiguousarray(rots, dtype=np.float64).reshape(-1, 3)
+        b = np.ascontiguousarray(bounds, dtype=np.float64)
+        pij = np.ascontiguousarray(probes, dtype=np.int32).reshape(-1, 2)
+        out = np.zeros((len(pij), cap, 2))
+        cnt = np.zeros(len(pij), dtype=np.int32)
+        err = C.create_string_buffer(512)
+        fn = self.lib.c5r_probe
+        fn.restype = C.c_int
+        rc = fn(_ptr(xyz, _dp), C.c_int64(len(xyz)), _ptr(cells, _ip), C.c_int64(len(cells)), _ptr(alpha, _dp), _ptr(q, _dp),
+                _ptr(rots, _dp), C.c_int(len(rots)), C.c_int(res_x), C.c_int(res_y), _ptr(b, _dp), _ptr(pij, _ip),
+                C.c_int(len(pij)), C.c_int(cap), _ptr(out, _dp), _ptr(cnt, _ip), err, C.c_int(512))
+        if rc != 0:
+            raise RuntimeError(err.value.decode())
+        return [out[k, :min(cnt[k], cap)].copy() for k in range(len(pij))]
+
     def scan_face(self, res_x, res_y, bounds, v0, v1, v2, cap=1 << 16):
         """Pixels (col, row) one projected face covers (plane.cpp:57-142), in emission order ("port" only)."""
         b = np.ascontiguousarray(bounds, dtype=np.float64)

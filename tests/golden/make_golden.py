@@ -66,6 +66,23 @@ def main():
             print(name, (ax, ay), "S", r["segments"], "covered", r["covered"], "max", img.max(axis=(0, 1)))
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
+    # G3: per-pixel segment lists of the reference's line::calculate_intersections (line.cpp:84-148) for 24 pixels of
+    # the G2 fixture, view (0.1, 0.07): [(tetra id, delta z)] in the order std::sort leaves them
+    xyz, cells, a, q = mg.workload("g2")
+    rots = mg.view_rotations(0.1, 0.07)
+    full = ref.render(xyz, cells, a, q, rots, 120, 90, mg.REFERENCE_BOUNDS)["image"]
+    cov = np.argwhere(full[..., 0] > 0)  # (row, col)
+    pick = cov[np.linspace(0, len(cov) - 1, 24).astype(int)]
+    probes = np.stack([pick[:, 1], pick[:, 0]], axis=1).astype(np.int32)
+    lists = ref.probe_segments(xyz, cells, a, q, rots, 120, 90, mg.REFERENCE_BOUNDS, probes)
+    g3 = dict(probes=probes, rots=rots, res=np.array([120, 90]), bounds=np.array(mg.REFERENCE_BOUNDS),
+              counts=np.array([len(l) for l in lists]))
+    for k, l in enumerate(lists):
+        g3[f"tet{k}"] = l[:, 0].astype(np.int64)
+        g3[f"dz{k}"] = l[:, 1]
+    np.savez_compressed(os.path.join(HERE, "g3_segments_g2_view1.npz"), **g3)
+    print("G3:", len(lists), "pixels,", int(g3["counts"].sum()), "segments")
+
     # rotation known-answer vectors (tetra.cpp:44-62 via the reference's tetra::rotate_around_*)
     rng = np.random.default_rng(7)
     pts = rng.uniform(-2, 2, (64, 3))

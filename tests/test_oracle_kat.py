@@ -67,3 +67,39 @@ def test_errors_are_reported_like_the_reference(oracle_port):
     bad[0, 0] = 99
     with pytest.raises(RuntimeError, match="out of range"):
         oracle_port.render(xyz, bad, a, q, np.zeros((0, 3)), 20, 20, mg.REFERENCE_BOUNDS)
+
+
+def test_per_pixel_segment_lists_equal_the_reference_golden_g3(oracle_port):
+    """G3: for 24 pixels of the G2 fixture the reference's own
+    line::calculate_intersections (line.cpp:84-148: plane solve per flagged face, swap, delta z, std::sort by
+    z_hi descending) left these (tetra id, delta z) sequences in line::_intersections_delta — read by the
+    inspection unit oracle/ref_inspect.cpp from the reference's object code (tests/golden/make_golden.py).
+    The oracle's restatement must reproduce ids, order and delta z bit for bit: this pins a10 / a11 on their own,
+    not only through the integrals."""
+    import os
+    from parity import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, "g3_segments_g2_view1.npz"))
+    xyz, cells, a, q = mg.workload("g2")
+    rx, ry = (int(v) for v in g["res"])
+    r = oracle_port.render(xyz, cells, a, q, g["rots"], rx, ry, g["bounds"], probes=g["probes"])
+    assert len(r["probes"]) == len(g["probes"]) == 24
+    total = 0
+    for k, seg in enumerate(r["probes"]):  # rows of (tet, z_hi, dz)
+        assert len(seg) == int(g["counts"][k]) > 0
+        assert np.array_equal(seg[:, 0].astype(np.int64), g[f"tet{k}"]), k
+        assert np.array_equal(seg[:, 2].view(np.uint64), g[f"dz{k}"].view(np.uint64)), k
+        assert (np.diff(seg[:, 1]) <= 0).all()  # sorted by z_hi, descending (line.cpp:78-82,138)
+        total += len(seg)
+    assert total == 220
+
+
+def test_inspection_build_agrees_with_the_committed_g3(oracle_ref):
+    """Where oracle/_ref is built (this container): the golden file is what the reference's object code says now."""
+    import os
+    from parity import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, "g3_segments_g2_view1.npz"))
+    xyz, cells, a, q = mg.workload("g2")
+    rx, ry = (int(v) for v in g["res"])
+    lists = oracle_ref.probe_segments(xyz, cells, a, q, g["rots"], rx, ry, g["bounds"], g["probes"])
+    for k, l in enumerate(lists):
+        assert np.array_equal(l[:, 0].astype(np.int64), g[f"tet{k}"]) and np.array_equal(l[:, 1].view(np.uint64), g[f"dz{k}"].view(np.uint64))
