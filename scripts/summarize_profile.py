@@ -17,6 +17,7 @@ import os
 import shutil
 import sys
 
+SUFFIX = ""
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 PROF = os.path.join(ROOT, "profiles")
@@ -88,7 +89,7 @@ def write_roofline(tag, walk, c):
         out["limiter"] = {"name": busiest[0], "frac": busiest[1],
                           "note": "the busiest unit; no unit is saturated - a step is a dependent chain (election -> load -> "
                                   "LDS -> geometry -> exit) and the resident wavefronts do not cover all of it"}
-    with open(os.path.join(PROF, "roofline.json"), "w") as f:
+    with open(os.path.join(PROF, f"roofline{SUFFIX}.json"), "w") as f:
         json.dump(out, f, indent=1)
     lines = [f"walk_composite per launch: {cycles:.4g} shader cycles" if cycles else ""]
     for k, v in units.items():
@@ -99,6 +100,8 @@ def write_roofline(tag, walk, c):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    global SUFFIX
+    SUFFIX = sys.argv[2] if len(sys.argv) > 2 else ""  # e.g. "_mixed": roofline_mixed.json, traffic is left alone
     os.makedirs(PROF, exist_ok=True)
     shutil.copy(os.path.join(OUT, "prof_kt", "kt_kernel_stats.csv"), os.path.join(PROF, f"{tag}_kernel_stats.csv"))
     counters = collections.defaultdict(dict)
@@ -128,8 +131,9 @@ def main():
                    "write_size_kib": write_kib,
                    "source": f"profiles/{tag}_pmc.md: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), "
                              "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per MI355X_MICROARCH.md HBM section"}
-        with open(os.path.join(PROF, "traffic.json"), "w") as f:
-            json.dump(traffic, f, indent=1)
+        if not SUFFIX:
+            with open(os.path.join(PROF, "traffic.json"), "w") as f:
+                json.dump(traffic, f, indent=1)
         lines += ["", f"walk_composite HBM bytes per launch = (2 x {fetch_kib:.0f} + {write_kib:.0f}) KiB = {hbm / 1e6:.1f} MB"]
         if "TCC_HIT_sum" in counters[walk]:
             h, m = counters[walk]["TCC_HIT_sum"][0], counters[walk]["TCC_MISS_sum"][0]
