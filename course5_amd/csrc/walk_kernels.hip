@@ -259,10 +259,11 @@ __global__ __launch_bounds__(256) void entry_raster(GridView g, const double* __
                 const unsigned want = n_more - taken;
                 unsigned base = cap_s;
                 if (lane == leader) {
-                    // a shard known to be full is passed by without touching its counter (the counters only
-                    // grow within a frame, so a stale reading errs on the side of asking)
+                    // The home shard is simply asked (one returning atomic, as before the ring).  On the way round
+                    // the ring a shard known to be full is passed by without touching its counter (the counters
+                    // only grow within a frame, so a stale reading errs on the side of asking).
                     unsigned* const used = &counters[shard].pool_used;
-                    if (__hip_atomic_load(used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cap_s) base = atomicAdd(used, want);
+                    if (t == 0 || __hip_atomic_load(used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cap_s) base = atomicAdd(used, want);
                 }
                 base = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(base), leader));
                 const unsigned avail = base < cap_s ? min(want, cap_s - base) : 0u;
