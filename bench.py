@@ -54,7 +54,7 @@ ROOFLINE_FILE = os.path.join(ROOT, "profiles", "roofline.json")  # written by sc
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=300)
+    p.add_argument("--steps", type=int, default=1000)
     p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--workload", default="c3", help="c3 (998 250 tets, default), c2, kuhnN")
     p.add_argument("--res", default="2400x1800", help="image size of the N = 1 workload")
@@ -208,6 +208,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+        # host-side barriers for the phases in which the GPUs must be left alone (an RCCL barrier is a kernel that
+        # spins on every GPU until the last rank arrives)
+        cpu_group = dist.new_group(backend="gloo") if args.backend == "nccl" else None
 
     res_x, res_y = (int(v) for v in args.res.lower().split("x"))
     base_res = (res_x, res_y)
@@ -402,7 +405,7 @@ def main():
     if not args.no_native and not args.solids and args.sweep == "none" and args.workload == "c3":
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=cpu_group)
         if rank == 0:
             k = max(20, min(args.steps, 200))
             if world == 1:
@@ -414,7 +417,7 @@ def main():
                             ("frames", ["--split", "frames"])]
             native = native_course_bench(xyz, cells, alpha, q, res_x, res_y, world, k, 20, variants)
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=cpu_group)
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
     seg = torch.tensor([stats["segments"], n_local * res_x, retries], dtype=torch.int64, device=rdev)
