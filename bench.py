@@ -399,6 +399,37 @@ def main():
                              "a face steep against the rays evaluated in fp64 (scalar loads); within the 1e-5 bar on every "
                              "parity test, not bit-faithful"}
 
+    # N > 1, second figure: the other way to use N GPUs — whole 2400x1800 frames, frame k on rank k mod N, nothing
+    # exchanged (how a sweep is rendered: BASELINE config 5; utility/rotate_traces.py runs one process per frame).
+    frames_mode = None
+    if world > 1 and sharded:
+        with torch.cuda.stream(stream):
+            ctx.set_row_range(0, -1)
+            ctx.set_row_tiles(0, 0, 1)
+            ctx.set_image(base_res[0], base_res[1], mg.REFERENCE_BOUNDS)
+            whole = torch.zeros((base_res[1], base_res[0], 2), dtype=torch.float32, device=dev)
+            for _ in range(3):
+                for _ in range(30):
+                    ctx.render_device(whole.data_ptr())
+                if ctx.synchronize() == capi.C5_OK:
+                    break
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                ctx.render_device(whole.data_ptr())
+            torch.cuda.synchronize()
+            dist.barrier()
+            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=rdev)
+            ok = torch.tensor([0 if ctx.synchronize() == capi.C5_OK else 1], dtype=torch.int64, device=rdev)
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(ok)
+            frames_mode = {"value": round(base_res[0] * base_res[1] * args.steps * world / float(dt.item()) / 1e6, 2),
+                           "unit": "Mrays/s", "ms_per_frame_per_gpu": round(float(dt.item()) * 1e3 / args.steps, 4),
+                           "frames": args.steps * world, "incomplete_frames_reported": int(ok.item()),
+                           "what": f"whole {base_res[0]}x{base_res[1]} frames, {args.steps} per GPU, frame k on rank k mod N, "
+                                   "grid replicated, no exchange; images stay in HBM"}
+
     # The C++ host on the same workload: rank 0 runs it as a child process on all N GPUs while the other ranks
     # idle at the barrier below (their GPUs are free: nothing of this job is running on them).
     native = None
@@ -502,6 +533,8 @@ def main():
             out["value_host_image"] = host_image
         if mixed is not None:
             out["value_mixed_precision"] = mixed
+        if frames_mode is not None:
+            out["value_whole_frames_per_gpu"] = frames_mode
         if native is not None:
             out["native_host"] = {"what": "the C++ host `course --bench` (one process, one c5_context per GPU) on the same grid, "
                                           "view and image; frames delivered to pinned host memory; Mrays/s in mrays_per_s",

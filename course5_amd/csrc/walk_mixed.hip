@@ -187,7 +187,7 @@ __device__ __forceinline__ double exp_nonpositive_local(double x) {
 }
 
 template <int TILE, int ORDER>
-__global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(80))) void walk_composite_mixed(WalkParams P) {
+__global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) void walk_composite_mixed(WalkParams P) {
     using TS = TileShape<TILE>;
     constexpr int TW = TS::WW * TS::GX, TH = TS::WH * TS::GY;
     constexpr bool kUp = (ORDER == 0);
@@ -315,7 +315,12 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(80))) void w
         //    one OptRecord each
         const uint32_t idg = static_cast<uint32_t>(my_elect[kMixBuckets + 64 + gslot]);
         const V4F stage_g = *reinterpret_cast<const V4F*>(geo_bytes + ((idg << 6) | geo_piece_off));
-        V4F stage_o = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wuninitialized"
+#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
+#pragma clang diagnostic ignored "-Wconditional-uninitialized"
+        V4F stage_o;  // lanes 16-63 leave it undefined; they never store it either
+#pragma clang diagnostic pop
         if (lane < 16) {
             const uint32_t ido = static_cast<uint32_t>(my_elect[kMixBuckets + 64 + lane]);
             stage_o = *reinterpret_cast<const V4F*>(opt_bytes + (ido << 4));
@@ -363,15 +368,18 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(80))) void w
             // "contributes" branch, one more round trip on the critical path.
             const V4F* r = reinterpret_cast<const V4F*>(reinterpret_cast<const char*>(my_stage) +
                                                         __umul24(static_cast<unsigned>(slot) & (kMixSlots - 1u), kMixStride * 16u));
-            V4F g0 = r[0], g1 = r[1], g2 = r[2], gwf = r[3], o = r[4];
-            asm volatile("" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(gwf), "+v"(o));
+            // (the optics go straight into the pending registers: free here, the previous step's emission is done,
+            // and only looked at again if this step contributes)
+            V4F g0 = r[0], g1 = r[1], g2 = r[2], gwf = r[3];
+            pend_opt = r[4];
+            asm volatile("" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(gwf), "+v"(pend_opt));
             if (slot >= kMixSlots) {  // more distinct cells than slots: rare in 8x8 tiles
                 const V4F* gr = reinterpret_cast<const V4F*>(P.geo + nb);
                 g0 = gr[0];
                 g1 = gr[1];
                 g2 = gr[2];
                 gwf = gr[3];
-                o = *reinterpret_cast<const V4F*>(P.opt32 + nb);
+                pend_opt = *reinterpret_cast<const V4F*>(P.opt32 + nb);
             }
             V4U gw;
             gw.x = __float_as_uint(gwf.x);
@@ -470,10 +478,9 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(80))) void w
             }
             if (dz > 0.0f && dz < INFINITY) {
                 ++n_seg;
-                tau = fma(dz_tau, static_cast<double>(o.x), tau);  // line.cpp:189 (unclamped alpha)
+                tau = fma(dz_tau, static_cast<double>(pend_opt.x), tau);  // line.cpp:189 (unclamped alpha)
                 pend = true;
                 pend_dz = dz;
-                pend_opt = o;
             }
             const uint32_t id = w_out & kIdMask;
             int nxt = static_cast<int>(id);
