@@ -78,17 +78,23 @@ __global__ __launch_bounds__(256) void build_records_mixed(GridView g, ImagePara
     // face that is steep against the rays makes them large and cancelling.  Bound them over the cell's own
     // footprint (they are largest at one of its vertices) and compare with the cell's extent along the rays:
     // beyond steep_ratio (option "steep_ratio") the cell is marked and the walk evaluates it from its fp64 record instead.
+    const double z_lo = fmin(fmin(v[0][2], v[1][2]), fmin(v[2][2], v[3][2]));
+    const double z_hi = fmax(fmax(v[0][2], v[1][2]), fmax(v[2][2], v[3][2]));
     double worst = 0.0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (!(fabs(c0[k]) <= DBL_MAX)) continue;  // edge-on / flat slot: +-inf, exact
         const double cabs = fabs(c0[k] - static_cast<double>(z0f));
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+            // only the face's own vertices bound its footprint: the fourth vertex is where the plane is
+            // extrapolated furthest, and no ray inside the cell sees the plane there.  (A vertex counts as the
+            // face's own if the plane passes through it; a sliver's fourth vertex may pass too: merely cautious.)
+            const double at_v = fma(r.plane[k][1], v[j][0] - r.x0, fma(r.plane[k][2], v[j][1] - r.y0, r.plane[k][0]));
+            if (fabs(at_v - v[j][2]) > 1e-6 * (z_hi - z_lo)) continue;
             worst = fmax(worst, cabs + fabs(r.plane[k][1] * (v[j][0] - Xc)) + fabs(r.plane[k][2] * (v[j][1] - Yr)));
+        }
     }
-    const double z_lo = fmin(fmin(v[0][2], v[1][2]), fmin(v[2][2], v[3][2]));
-    const double z_hi = fmax(fmax(v[0][2], v[1][2]), fmax(v[2][2], v[3][2]));
     const bool steep = steep_ratio > 0.0 && !(worst <= steep_ratio * (z_hi - z_lo));  // (NaN -> steep)
     if (steep) {
         const U4* rs = reinterpret_cast<const U4*>(&r);
