@@ -74,12 +74,18 @@ if rank == 0:
     full = capi.Context(0)
     full.upload_grid(xyz, cells, alpha, q)
     full.set_image(res_x, res_y, mg.REFERENCE_BOUNDS)
+    from oracle.pyoracle import Oracle  # the checker: the reassembled frames also against the CPU oracle
+    oracle = Oracle("port")
     for k, v in enumerate(views):
         full.set_view(v)
         want = full.render()
         same = np.array_equal(got[k].view(np.uint32), want.view(np.uint32))
-        ok &= same
-        print(f"{layout} frame {k}: {'equal' if same else 'DIFFERENT'}", flush=True)
+        ref = oracle.render(xyz, cells, alpha, q, v, res_x, res_y, mg.REFERENCE_BOUNDS, threads=4)["image"]
+        a, b = got[k].astype(np.float64), ref.astype(np.float64)
+        close = bool((np.abs(a - b) <= 1e-5 * np.maximum(np.abs(a), np.abs(b)) + 1e-6 * np.abs(b).max()).all())
+        ok &= same and close
+        print(f"{layout} frame {k}: {'equal' if same else 'DIFFERENT'} to the single-context render, "
+              f"{'within' if close else 'BEYOND'} 1e-5 of the oracle", flush=True)
     same = np.array_equal(last.cpu().numpy().view(np.uint32), want.view(np.uint32))
     ok &= same
     print(f"{layout} last frame of the back-to-back burst: {'equal' if same else 'DIFFERENT'}", flush=True)
