@@ -1,6 +1,6 @@
 """Randomised parity sweep: GPU (C ABI) vs CPU oracle on many small random scenes.
 
-    python scripts/fuzz_parity.py [n_scenes] [seed0]
+    python tests/fuzz_parity.py [n_scenes] [seed0]
 
 Scenes: jittered Kuhn boxes with random cells removed (holes, non-convex, disconnected parts),
 random anisotropic scaling / placement inside the domain, random views, scalars including zeros

@@ -1,4 +1,4 @@
-"""Bounded randomised parity sweep on the GPU (scripts/fuzz_parity.py holds the scene generator):
+"""Bounded randomised parity sweep on the GPU (tests/fuzz_parity.py holds the scene generator):
 random grids with holes / disconnected parts / anisotropic scaling, random views, scalars, image
 sizes and kernel variants, each compared with the CPU oracle."""
 import importlib.util
@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _fuzz():
-    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "scripts", "fuzz_parity.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "tests", "fuzz_parity.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod

@@ -1,7 +1,7 @@
 """N = 2 rehearsal of the multi-GPU frame pipeline on the ONE GPU of the test box: two ranks (gloo, both
 on device 0, strips staged through the host) render their row tiles / blocks through FramePipeline —
 side-stream reassembly, two gathers in flight — and every reassembled frame must equal the
-single-context render bit for bit (scripts/two_rank_check.py).  The RCCL transport itself cannot be
+single-context render bit for bit (tests/two_rank_check.py).  The RCCL transport itself cannot be
 exercised on one GPU; everything around it is."""
 import os
 import subprocess
@@ -26,7 +26,7 @@ def test_two_ranks_reassemble_every_frame(layout, extra):
         port = str(sock.getsockname()[1])
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", port,
-                        os.path.join(ROOT, "scripts", "two_rank_check.py"), layout],
+                        os.path.join(ROOT, "tests", "two_rank_check.py"), layout],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "PASS" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
     if extra:

@@ -2,7 +2,7 @@
 the host): every frame rank 0 reassembles must equal the single-context render of the same view.
 
     C5_BENCH_ONE_DEVICE=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
-        --master-addr 127.0.0.1 --master-port 29533 scripts/two_rank_check.py [cyclic|blocks]
+        --master-addr 127.0.0.1 --master-port 29533 tests/two_rank_check.py [cyclic|blocks]
 """
 import os
 import sys
