@@ -175,8 +175,13 @@ __global__ __launch_bounds__(256) void entry_raster(GridView g, const double* __
     const double ec2 = -(ea2 * (cx - ax) + eb2 * (cy - ay));
     const float inv_bw = 1.0f / static_cast<float>(bw);
     const bool small_box = n_box < (1u << 24);  // float(idx) exact: the estimate is off by one at most
-    // Four 64-pixel chunks of the box per iteration: their four returning atomics are in flight together.
-    constexpr int kChunks = 4;
+    // Two 64-pixel chunks of the box per iteration, their returning atomics in flight together.  Measured on the C3
+    // frame / the C2 ball (entry_raster, us): 1 chunk 50 / 20.8, 2 chunks 47 / 20.6, 3 -> 49 / 21.3, 4 -> 52 / 22.3,
+    // 8 -> 55 / 24.3: a face's box holds ~400 pixels, and wider iterations end in mostly idle ones.
+#ifndef C5_RASTER_CHUNKS
+#define C5_RASTER_CHUNKS 2
+#endif
+    constexpr int kChunks = C5_RASTER_CHUNKS;
     for (unsigned base = 0; base < n_box; base += 64u * kChunks) {
         bool in[kChunks];
         size_t lp[kChunks];
