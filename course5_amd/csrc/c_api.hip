@@ -93,6 +93,8 @@ struct c5_context {
     hipStream_t aux_stream = nullptr;  // per-view setup of the next frame
     hipStream_t side_stream = nullptr; // entry lists + solid mask beside build_records
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    int fuse_setup = 0;     // build_records + entry_raster as one launch of interleaved workgroups: measured 0.119 ms against
+                            // 0.047 + 0.047 ms for the two launches on the C3 frame (the raster inherits the records' 49 KB of LDS)
     int overlap_setup = 0;  // measured: 1.27 vs 1.26 ms/frame, the side stream buys nothing
     DeviceBuffer px, py, pz, cell_vert, cell_adj, alpha, q, bface;
     FrameSlot slots[kFrameSlots];
@@ -421,14 +423,22 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
         g.opt32 = fs.opt32.as<c5::OptRecord>();
         g.z0 = fs.z0.as<float>();
         c5::launch_build_records_mixed(s, g, im, ctx->xtab.as<double>(), ctx->ytab.as<double>(), ctx->alpha_limit, ctx->order, ctx->steep_ratio);
-    } else {
+    } else if (!(ctx->fuse_setup && !side && g.n_cells > 0)) {
         c5::launch_build_records(s, g, ctx->alpha_limit, ctx->order);
     }
-    C5_HIP(ctx, mark(2, s));
+    const bool fused = !mixed && ctx->fuse_setup && !side && g.n_cells > 0;
+    if (!fused) C5_HIP(ctx, mark(2, s));
     // boundary entries: one raster pass (per-pixel count + first entry + overflow chain)
     if (!fs.head_clean) C5_HIP(ctx, hipMemsetAsync(fs.head.ptr, 0, static_cast<size_t>(padded) * sizeof(c5::EntryHead), e));
     fs.head_clean = false;
-    if (g.n_cells > 0) {
+    if (fused) {
+        // records and entry lists as ONE launch of interleaved workgroups ("fuse_setup"; ms_records then holds the
+        // time of both and ms_entries is zero)
+        c5::launch_setup_fused(s, g, ctx->alpha_limit, ctx->order, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im,
+                               fs.head.as<c5::EntryHead>(), fs.first.as<c5::Entry>(), fs.pool.as<c5::Entry>(), fs.entry_capacity,
+                               fs.counters.as<c5::FrameCounters>(), ctx->sticky.as<unsigned>(), ctx->order != 0);
+        C5_HIP(ctx, mark(2, s));
+    } else if (g.n_cells > 0) {
         c5::launch_entry_lists(e, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im, fs.head.as<c5::EntryHead>(),
                                fs.first.as<c5::Entry>(), fs.pool.as<c5::Entry>(), fs.entry_capacity,
                                fs.counters.as<c5::FrameCounters>(), ctx->sticky.as<unsigned>(), ctx->order != 0);
@@ -1050,6 +1060,8 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
         if (ctx->n_cells > 0 || ctx->have_image)
             return fail(ctx, C5_ERR_STATE, "set \"pipeline\" before uploading the grid and setting the image");
         ctx->pipeline = static_cast<int>(value) != 0;
+    } else if (n == "fuse_setup") {
+        ctx->fuse_setup = static_cast<int>(value) != 0;
     } else if (n == "overlap_setup") {
         ctx->overlap_setup = static_cast<int>(value) != 0;
     } else if (n == "algorithm") {

@@ -85,6 +85,10 @@ void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, 
 void launch_entry_lists(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
                         const ImageParams& im, EntryHead* head, Entry* first, Entry* pool, int64_t capacity,
                         FrameCounters* counters, unsigned* sticky, int want_upper);
+// build_records and entry_raster as one launch of interleaved workgroups
+void launch_setup_fused(hipStream_t s, const GridView& g, double alpha_limit, int order, const double* Xtab, const double* Ytab,
+                        const ImageParams& im, EntryHead* head, Entry* first, Entry* pool, int64_t capacity,
+                        FrameCounters* counters, unsigned* sticky, int want_upper);
 void launch_walk(hipStream_t s, const WalkParams& p, int tile_shape);
 
 // walk_mixed.hip ("precision" 1)

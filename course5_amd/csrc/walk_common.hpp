@@ -282,4 +282,242 @@ __device__ __forceinline__ int next_entry(const WalkParams& P, size_t lp, EntryH
 }
 
 
+// ------------------------------------------------------------------------------------------
+// entry_raster: one wavefront per boundary face, ONE pass.
+//
+// Per covered pixel: old = atomicAdd(head[pixel].count, 1).  The first entry of a pixel (old == 0)
+// goes straight into the dense array first[pixel] as one full 16-byte store; every further one
+// (re-entry of a non-convex grid: rare) takes a slot of the overflow pool and hooks itself into the
+// pixel's chain with one atomicExch on head[pixel].chain (slot + 1; 0 ends a chain).  The walk reads
+// head[pixel], first[pixel] and the chain.  No scan over the pixels and no second raster pass
+// (count -> scan -> fill took 35 + 30 + 52 us on the C3 frame); first[] is never cleared, only the
+// 8-byte heads are.
+// ------------------------------------------------------------------------------------------
+struct RasterArgs {
+    const double* Xtab;
+    const double* Ytab;
+    ImageParams im;
+    EntryHead* head;
+    Entry* first;
+    Entry* pool;
+    int64_t capacity;
+    FrameCounters* counters;
+    unsigned* sticky;
+    int want_upper;
+};
+
+// The work of one workgroup (four boundary faces); `block` is its index among the raster workgroups, so that
+// the same body serves the stand-alone kernel and the fused per-view setup launch.
+__device__ __forceinline__ void entry_raster_block(const GridView& g, const RasterArgs& A, unsigned block) {
+    const double* __restrict__ Xtab = A.Xtab;
+    const double* __restrict__ Ytab = A.Ytab;
+    const ImageParams& im = A.im;
+    EntryHead* __restrict__ head = A.head;
+    Entry* __restrict__ first = A.first;
+    Entry* __restrict__ pool = A.pool;
+    const int64_t capacity = A.capacity;
+    FrameCounters* counters = A.counters;
+    unsigned* sticky = A.sticky;
+    const int want_upper = A.want_upper;
+    const int lane = threadIdx.x & 63;
+    const int64_t face_idx = block * 4ll + (threadIdx.x >> 6);
+    if (face_idx >= g.n_bfaces) return;
+    const uint32_t bf = g.bface[face_idx];
+    const uint32_t cell = bf >> 2;
+    const int f = static_cast<int>(bf & 3u);
+    const int4 cv = g.cell_vert[cell];
+    const int vid[4] = {cv.x, cv.y, cv.z, cv.w};
+    double p[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p[k][1] = g.vy[vid[k]];
+    // same band test as build_records: a culled cell has no record and no ray of this context
+    if (fmax(fmax(p[0][1], p[1][1]), fmax(p[2][1], p[3][1])) < g.cull_y_lo ||
+        fmin(fmin(p[0][1], p[1][1]), fmin(p[2][1], p[3][1])) > g.cull_y_hi)
+        return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        p[k][0] = g.vx[vid[k]];
+        p[k][2] = g.vz[vid[k]];
+    }
+    FacePlane fp;
+    switch (f) {  // constant face index per case keeps the vertex selection in registers
+        case 0: fp = face_plane(p, 0); break;
+        case 1: fp = face_plane(p, 1); break;
+        case 2: fp = face_plane(p, 2); break;
+        default: fp = face_plane(p, 3); break;
+    }
+    // walking from +z to -z a ray enters through faces the cell body lies below (upper faces);
+    // walking from -z to +z through the others
+    if (fp.kind == 0 || ((fp.kind > 0) != (want_upper != 0))) return;
+
+    const int i0 = (f == 3) ? 1 : 0;
+    const int i1 = (f <= 1) ? 1 : 2;
+    const int i2 = (f == 0) ? 2 : 3;
+    double ax, ay, bx, by, cx, cy;
+    {   // selects, not runtime indexing
+        ax = i0 == 0 ? p[0][0] : p[1][0];
+        ay = i0 == 0 ? p[0][1] : p[1][1];
+        bx = i1 == 1 ? p[1][0] : p[2][0];
+        by = i1 == 1 ? p[1][1] : p[2][1];
+        cx = i2 == 2 ? p[2][0] : p[3][0];
+        cy = i2 == 2 ? p[2][1] : p[3][1];
+    }
+
+    const double xmin = fmin(ax, fmin(bx, cx)), xmax = fmax(ax, fmax(bx, cx));
+    const double ymin = fmin(ay, fmin(by, cy)), ymax = fmax(ay, fmax(by, cy));
+    // conservative pixel box: floor / ceil already include a pixel on either side whose centre lies outside
+    // the face (the pixel coordinates are running sums, off from x_min + i * step by ~1e-13 of a pixel: far
+    // less than that margin needs)
+    double fc0 = floor((xmin - im.x_min) / im.step_x);
+    double fc1 = ceil((xmax - im.x_min) / im.step_x);
+    double fr0 = floor((ymin - im.y_min) / im.step_y);
+    double fr1 = ceil((ymax - im.y_min) / im.step_y);
+    if (!(fc1 >= 0.0) || !(fr1 >= 0.0) || !(fc0 <= im.res_x - 1.0) || !(fr0 <= im.res_y - 1.0)) return;
+    const int c0 = static_cast<int>(fmax(fc0, 0.0));
+    const int c1 = static_cast<int>(fmin(fc1, im.res_x - 1.0));
+    const int r0 = max(static_cast<int>(fmax(fr0, 0.0)), im.row_begin);
+    const int r1 = min(static_cast<int>(fmin(fr1, im.res_y - 1.0)), im.row_begin + im.row_count - 1);
+    if (r1 < r0) return;
+    // only the rows of this context (cyclic row tiles: every world-th tile), as a range of LOCAL rows
+    int lr0, lr1;
+    local_row_span(im, r0, r1, lr0, lr1);
+    if (lr1 < lr0) return;
+    const unsigned bw = static_cast<unsigned>(c1 - c0 + 1);
+    const unsigned n_box = bw * static_cast<unsigned>(lr1 - lr0 + 1);  // <= pixels of the image: fits 32 bits
+
+    const double x0 = p[0][0], y0 = p[0][1];
+    const double pc = fp.c, pgx = fp.gx, pgy = fp.gy;
+
+    // The raster is bound by vector instructions (the box of a face holds 2.5x the pixels of the face), so
+    // the per-pixel work is kept small: the three edge functions as planes about vertex a (two fused
+    // multiply-adds each; which of two faces claims a pixel within rounding of their common edge was never
+    // defined by the older product form either) and the row / column split by a float reciprocal with a
+    // one-step correction instead of an integer division.
+    const double ea0 = -(by - ay), eb0 = bx - ax;                       // edge a -> b
+    const double ea1 = -(cy - by), eb1 = cx - bx;                       // edge b -> c
+    const double ec1 = -(ea1 * (bx - ax) + eb1 * (by - ay));
+    const double ea2 = -(ay - cy), eb2 = ax - cx;                       // edge c -> a
+    const double ec2 = -(ea2 * (cx - ax) + eb2 * (cy - ay));
+    const float inv_bw = 1.0f / static_cast<float>(bw);
+    const bool small_box = n_box < (1u << 24);  // float(idx) exact: the estimate is off by one at most
+    // Two 64-pixel chunks of the box per iteration, their returning atomics in flight together.  Measured on the C3
+    // frame / the C2 ball (entry_raster, us): 1 chunk 50 / 20.8, 2 chunks 47 / 20.6, 3 -> 49 / 21.3, 4 -> 52 / 22.3,
+    // 8 -> 55 / 24.3: a face's box holds ~400 pixels, and wider iterations end in mostly idle ones.
+#ifndef C5_RASTER_CHUNKS
+#define C5_RASTER_CHUNKS 2
+#endif
+    constexpr int kChunks = C5_RASTER_CHUNKS;
+    for (unsigned base = 0; base < n_box; base += 64u * kChunks) {
+        bool in[kChunks];
+        size_t lp[kChunks];
+        double z[kChunks];
+        int old[kChunks];
+#pragma unroll
+        for (int k = 0; k < kChunks; ++k) {
+            const unsigned idx = base + 64u * k + static_cast<unsigned>(lane);
+            in[k] = false;
+            lp[k] = 0;
+            z[k] = 0.0;
+            if (idx < n_box) {
+                unsigned qrow, rcol;
+                if (small_box) {
+                    qrow = static_cast<unsigned>(static_cast<float>(idx) * inv_bw);
+                    int rem = static_cast<int>(idx - qrow * bw);
+                    if (rem < 0) {
+                        qrow -= 1u;
+                        rem += static_cast<int>(bw);
+                    } else if (rem >= static_cast<int>(bw)) {
+                        qrow += 1u;
+                        rem -= static_cast<int>(bw);
+                    }
+                    rcol = static_cast<unsigned>(rem);
+                } else {
+                    qrow = idx / bw;
+                    rcol = idx - qrow * bw;
+                }
+                const int lrow = lr0 + static_cast<int>(qrow);
+                const int row = global_row_of(im, lrow);
+                const int col = c0 + static_cast<int>(rcol);
+                {
+                    const double x = Xtab[col], y = Ytab[row];
+                    // closed point-in-triangle test, either winding
+                    const double dxa = x - ax, dya = y - ay;
+                    const double e0 = fma(ea0, dxa, eb0 * dya);
+                    const double e1 = fma(ea1, dxa, fma(eb1, dya, ec1));
+                    const double e2 = fma(ea2, dxa, fma(eb2, dya, ec2));
+                    in[k] = (e0 >= 0 && e1 >= 0 && e2 >= 0) || (e0 <= 0 && e1 <= 0 && e2 <= 0);
+                    lp[k] = static_cast<size_t>(lrow) * im.res_x + col;
+                    z[k] = pc + pgx * (x - x0) + pgy * (y - y0);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kChunks; ++k) old[k] = in[k] ? atomicAdd(&head[lp[k]].count, 1) : 0;
+#pragma unroll
+        for (int k = 0; k < kChunks; ++k) {
+            if (in[k] && old[k] == 0) {
+                Entry e;
+                e.z = z[k];
+                e.cell = static_cast<int32_t>(cell);
+                e.next = 0;
+                first[lp[k]] = e;
+            }
+            // further entries: one pool allocation per wavefront and chunk (same-address atomics serialise)
+            const bool more = in[k] && old[k] > 0;
+            const unsigned long long more_mask = __builtin_amdgcn_ballot_w64(more);
+            if (more_mask == 0ull) continue;
+            // The pool is cut into kCounterShards parts, each with its counter on a line of its own (a
+            // non-convex grid makes tens of thousands of these allocations per frame; on ONE word they
+            // would serialise at ~10 ns each).  A request starts at its home shard and takes what that shard
+            // has left; what it still lacks it asks of the next shard, and so on round the ring: a slot is
+            // refused only when every shard is exhausted, i.e. a frame overflows if and only if its TOTAL
+            // demand (sum over the pixels of entries - 1, a property of grid, view and image alone)
+            // exceeds the capacity — never because of which faces hash to which shard or of the order
+            // the entries of a pixel arrive in.  (Round 1 gave every shard a fixed capacity / 64: one
+            // large re-entry face could overflow its shard with 63 others empty, and which entry of a
+            // pixel needs a slot at all is a race, so the same frame overflowed or not from run to run.)
+            const unsigned n_more = static_cast<unsigned>(__popcll(more_mask));
+            const unsigned my_rank = static_cast<unsigned>(__popcll(more_mask & ((1ull << lane) - 1ull)));
+            const int leader = __builtin_ctzll(more_mask);
+            unsigned shard = static_cast<unsigned>(face_idx) % kCounterShards;
+            unsigned taken = 0;  // wave-uniform: requests served so far
+            long long slot = -1;
+            for (int t = 0; t < kCounterShards && taken < n_more; ++t, shard = (shard + 1u) % kCounterShards) {
+                const unsigned lo = static_cast<unsigned>((static_cast<unsigned long long>(shard) * static_cast<unsigned long long>(capacity)) / kCounterShards);
+                const unsigned hi = static_cast<unsigned>((static_cast<unsigned long long>(shard + 1u) * static_cast<unsigned long long>(capacity)) / kCounterShards);
+                const unsigned cap_s = hi - lo;
+                const unsigned want = n_more - taken;
+                unsigned base = cap_s;
+                if (lane == leader) {
+                    // The home shard is simply asked (one returning atomic, as before the ring).  On the way round
+                    // the ring a shard known to be full is passed by without touching its counter (the counters
+                    // only grow within a frame, so a stale reading errs on the side of asking).
+                    unsigned* const used = &counters[shard].pool_used;
+                    if (t == 0 || __hip_atomic_load(used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cap_s) base = atomicAdd(used, want);
+                }
+                base = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(base), leader));
+                const unsigned avail = base < cap_s ? min(want, cap_s - base) : 0u;
+                if (more && my_rank >= taken && my_rank < taken + avail) slot = static_cast<long long>(lo) + base + (my_rank - taken);
+                taken += avail;
+            }
+            if (more && slot >= 0) {
+                Entry e;
+                e.z = z[k];
+                e.cell = static_cast<int32_t>(cell);
+                e.next = atomicExch(&head[lp[k]].chain, static_cast<int32_t>(slot) + 1);
+                pool[slot] = e;
+            }
+            if (taken < n_more && lane == leader) {
+                // pool exhausted: the frame is incomplete.  The host reads the number of entries that found
+                // no slot (this frame: counters[0].entry_overflow; any frame since it last looked: sticky[0]),
+                // grows the pool by at least that and reports C5_RETRY; the walk bounds-checks every hop,
+                // so such a frame is wrong but never unsafe.
+                atomicAdd(&counters->entry_overflow, n_more - taken);
+                atomicAdd(sticky, n_more - taken);
+            }
+        }
+    }
+}
+
+
 }  // namespace c5

@@ -167,6 +167,8 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *   "xcd_mode"     how workgroups map to the 8 XCDs (blocks b and b + 8 share an L2): 2 (default): square
  *                  super-blocks of workgroups dealt round-robin; 1: bands of image rows; 0: row-major tiles.
  *   "band_rows"    tuning: rows per super-block ("xcd_mode" 2, 0 = default 32) or band (1, default 16).
+ *   "fuse_setup"   1: the per-cell records and the boundary entry lists are built by ONE launch of interleaved
+ *                  workgroups; 0 (default): two launches.  Same results; measured slower fused.
  *   "overlap_setup" 1: entry lists and solid mask are built on a side stream while build_records
  *                  runs (only when "stage_timing" is 0).  Default 0: measured no faster.
  *   "pipeline"     1: two frame slots; the per-view setup of frame k + 1 runs on a second stream while
