@@ -1,0 +1,77 @@
+// Helpers shared by the mixed-precision walk kernels (walk_mixed.hip: one ray per lane; walk_mixed2.hip: two).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+#include "device_types.hpp"
+#include "kernels.hpp"
+#include "walk_common.hpp"
+
+namespace c5 {
+
+constexpr uint32_t kExactBit = 1u << 29;  // GeoRecord::w[0]: evaluate this cell from its fp64 CellRecord
+
+constexpr int kMixSlots = 16;        // distinct cells staged per wavefront and step: ONE load instruction
+constexpr int kMixStride = 5;        // 16-byte units per slot: 4 of GeoRecord + 1 of OptRecord.  80 bytes = 20
+                                     // banks: sixteen slots start on sixteen different 16-byte bank columns
+constexpr unsigned kMixBuckets = 256;
+
+using V4F = float __attribute__((ext_vector_type(4)));
+using SRec16 = int __attribute__((ext_vector_type(16)));  // half a CellRecord in scalar registers
+using V4U = uint32_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float min3_f32(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max3_f32(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// e^x - 1 for -1/8 < x <= 0 in fp32: x (1 + x/2 (1 + x/3 (...))) to x^7 (truncation 5e-10 relative)
+__device__ __forceinline__ float expm1_small(float x) {
+    float p = fmaf(x, 1.0f / 5040.0f, 1.0f / 720.0f);
+    p = fmaf(p, x, 1.0f / 120.0f);
+    p = fmaf(p, x, 1.0f / 24.0f);
+    p = fmaf(p, x, 1.0f / 6.0f);
+    p = fmaf(p, x, 0.5f);
+    p = fmaf(p, x, 1.0f);
+    return p * x;
+}
+
+// exp(x) for x <= 0, the general case (|alpha dz| >= 1/8: rare in this kernel).  exp_nonpositive keeps its
+// coefficients in scalar registers for the whole loop — twenty SGPRs, which here would cost a wavefront per SIMD —
+// so this copy materialises each constant where it is used (the empty asm keeps it from being hoisted).
+__device__ __forceinline__ double exp_nonpositive_local(double x) {
+#pragma clang fp contract(fast)
+    auto local = [](double c) {
+        asm volatile("" : "+s"(c));
+        return c;
+    };
+    x = fmax(x, local(-746.0));
+    const double k = rint(x * local(1.4426950408889634074));
+    double r = fma(k, local(-6.93147180369123816490e-01), x);
+    r = fma(k, local(-1.90821492927058770002e-10), r);
+    double p = fma(local(1.0 / 6227020800.0), r, local(1.0 / 479001600.0));
+    p = fma(p, r, local(1.0 / 39916800.0));
+    p = fma(p, r, local(1.0 / 3628800.0));
+    p = fma(p, r, local(1.0 / 362880.0));
+    p = fma(p, r, local(1.0 / 40320.0));
+    p = fma(p, r, local(1.0 / 5040.0));
+    p = fma(p, r, local(1.0 / 720.0));
+    p = fma(p, r, local(1.0 / 120.0));
+    p = fma(p, r, local(1.0 / 24.0));
+    p = fma(p, r, local(1.0 / 6.0));
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, static_cast<int>(k));
+}
+
+
+}  // namespace c5
