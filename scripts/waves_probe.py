@@ -16,7 +16,8 @@ def run(n):
         ctx.render_device(out.data_ptr())
     ctx.synchronize()
     return ctx.walk_kernel_ms(reset=True)[0]
-for prec in (0, 1):
+for prec, rays in ((0, 1), (1, 1), (1, 2), (1, 1), (1, 2)):
     ctx.set_option("precision", prec)
+    ctx.set_option("rays_per_lane", rays)
     run(200)
-    print(capi.LIB_PATH.split("/")[-1], "precision", prec, "walk %.4f ms" % run(400), flush=True)
+    print(capi.LIB_PATH.split("/")[-1], "precision", prec, "rays per lane", rays, "walk %.4f ms" % run(400), flush=True)
