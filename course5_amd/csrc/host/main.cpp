@@ -221,6 +221,11 @@ int main(int argc, char** argv) try {
             const auto t3 = timestamp();
             std::cout << config.frames - 1 << " further frames in " << ms_between(t2, t3) << " ms. " << std::endl;
         }
+        if (config.print_stats) {
+            std::size_t again = 0;
+            for (const auto& p : planes) again += p->retries();
+            std::cout << "Frames rendered again after an internal buffer grew: " << again << std::endl;
+        }
     } else {
         // --bench: frames rendered and delivered to host memory, no files.  One JSON line.
         for (std::size_t k = 0; k < config.bench_warmup; ++k) {

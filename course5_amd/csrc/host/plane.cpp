@@ -8,6 +8,7 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <iostream>
 #include <stdexcept>
 
@@ -263,6 +264,10 @@ plane::plane(std::size_t res_x, std::size_t res_y, std::vector<object3d_base> ob
         check(c5_set_image(ctx, static_cast<int>(res_x), static_cast<int>(res_y), global_boundaries.data()), "c5_set_image", k);
         check(c5_set_alpha_limit(ctx, app::instance().config.limit_alpha_value), "c5_set_alpha_limit", k);  // line.cpp:204
         if (app::instance().config.reference_algorithm) check(c5_set_option(ctx, "algorithm", 1.0), "c5_set_option", k);
+        // test hook: start from an overflow pool of this many records, so that the C5_RETRY handling of trace_rays
+        // (frames in flight rendered again, in order, each with its own views) is exercised end to end
+        if (const char* starve = std::getenv("C5_TEST_ENTRY_POOL"))
+            check(c5_set_option(ctx, "entry_pool", std::atof(starve)), "c5_set_option", k);
     }
     update_views(objects3d);
     _pool = std::make_shared<image_pool>(res_x * res_y * 2 * sizeof(float));

@@ -193,3 +193,34 @@ def test_course_automatic_boundaries(tmp_path, oracle_port):
     d = np.abs(got.astype(np.float64) - want.astype(np.float64))
     bad = d > 1e-5 * np.maximum(np.abs(got), np.abs(want)) + 1e-6 * np.abs(want).max()
     assert bad.sum() <= 8 and (got[..., 0] > 0).sum() > 20_000
+
+
+def test_course_sweep_survives_a_starved_entry_pool(tmp_path):
+    """plane::trace_rays' C5_RETRY handling end to end: a sweep over the non-convex ball started from an overflow
+    pool of 100 records (test hook C5_TEST_ENTRY_POOL), frames issued ahead.  The frame that overflows and the
+    frames already in flight behind it are rendered again, in order, each with its own view: every file equals
+    the one of an undisturbed run, and the run says that it had to render frames again."""
+    xyz, cells, a, q = mg.workload("c2")
+    src = tmp_path / "c2.vtk"
+    mg.write_vtk_binary(str(src), xyz, cells, a, q)
+    common = ["-f", src, "-x", 500, "-y", 375, "-X", 0.1, "-Y", 0.07, "--no_solids", "--frames", 6, "--sweep", "Y",
+              "--sweep_step", 0.05, "--raw_vti", "--stats", "-j4"]
+    _run(common + ["-d", tmp_path / "calm.vti"])
+    env = dict(os.environ, C5_TEST_ENTRY_POOL="100")
+    r = subprocess.run([COURSE] + [str(x) for x in common + ["-d", tmp_path / "starved.vti"]], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-1000:]
+    again = [int(line.rsplit(":", 1)[1]) for line in r.stdout.splitlines() if line.startswith("Frames rendered again")]
+    assert again and again[0] >= 1
+    for k in range(6):
+        calm, _ = vtkio.read_vti(str(tmp_path / f"calm_{k:05d}.vti"))
+        starved, _ = vtkio.read_vti(str(tmp_path / f"starved_{k:05d}.vti"))
+        assert np.array_equal(calm, starved), k
+    for devices in ("0,0",):  # the same with the rows of every frame split over two contexts
+        r = subprocess.run([COURSE] + [str(x) for x in common + ["-d", tmp_path / "two.vti", "--devices", devices, "--split", "rows"]],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-1000:]
+        for k in range(6):
+            calm, _ = vtkio.read_vti(str(tmp_path / f"calm_{k:05d}.vti"))
+            two, _ = vtkio.read_vti(str(tmp_path / f"two_{k:05d}.vti"))
+            assert np.array_equal(calm, two), k
