@@ -42,6 +42,9 @@ const option_spec kOptions[] = {
     {"auto_bounds", 0, false, "image domain = bounding box of the transformed objects instead of the fixed domain", nullptr},
     {"no_solids", 0, false, "do not generate the Roche lobe and the accretor sphere", nullptr},
     {"stats", 0, false, "print per-stage GPU timings and segment counts", nullptr},
+    {"png", 0, false, "also write a colour-mapped PNG (Cool to Warm, NaN yellow) of one channel beside every .vti", nullptr},
+    {"png_channel", 0, true, "channel of the PNG: 0 (optical depth) or 1 (intensity)", "1"},
+    {"png_range", 0, true, "lo,hi: fixed colour range for every frame (default: each frame's own finite range)", nullptr},
     {"raw_vti", 0, false, "write the .vti uncompressed (default: zlib blocks, like vtkXMLImageDataWriter)", nullptr},
     {"reference_algorithm", 0, false, "bin + sort + resolve on the GPU (for grids with overlapping cells)", nullptr},
     {"selftest_vti", 0, true, "write a synthetic 48x32 image to this .vti and exit (checks the writer, no GPU)", nullptr},
@@ -132,6 +135,18 @@ bool program_options(int argc, char** argv, std::ostream& out) {
         else if (n == "no_solids") cfg.no_solids = true;
         else if (n == "stats") cfg.print_stats = true;
         else if (n == "raw_vti") cfg.raw_vti = true;
+        else if (n == "png") cfg.png = true;
+        else if (n == "png_channel") {
+            cfg.png_channel = static_cast<int>(to_integer(n, v));
+            if (cfg.png_channel != 0 && cfg.png_channel != 1)
+                throw std::runtime_error("the argument ('" + v + "') for option '--png_channel' is invalid");
+        } else if (n == "png_range") {
+            const auto comma = v.find(',');
+            if (comma == std::string::npos) throw std::runtime_error("the argument ('" + v + "') for option '--png_range' is invalid");
+            cfg.png_lo = to_double(n, v.substr(0, comma));
+            cfg.png_hi = to_double(n, v.substr(comma + 1));
+            cfg.png_fixed_range = true;
+        }
         else if (n == "reference_algorithm") cfg.reference_algorithm = true;
         else if (n == "selftest_vti") cfg.selftest_vti = v;
         else if (n == "parse_only") cfg.parse_only = true;

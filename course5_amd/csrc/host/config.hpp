@@ -32,6 +32,10 @@ struct render_config {
     bool no_solids = false;
     bool print_stats = false;
     bool parse_only = false;      // read the input, generate the solids, report sizes, no GPU work
+    bool png = false;             // beside every .vti a colour-mapped .png of one channel (what utility/screen.py makes with ParaView)
+    int png_channel = 1;          // 0: tau, 1: I (screen.py:11 colours by component 'Y')
+    bool png_fixed_range = false; // false: every frame mapped over its own finite range, as ParaView does on load
+    double png_lo = 0, png_hi = 0;
     bool raw_vti = false;         // write uncompressed appended data instead of zlib blocks
     bool reference_algorithm = false;  // force the bin-sort-resolve path (tet soups with overlapping cells)
     std::string selftest_vti;     // write a small synthetic image with the configured encoding and exit (no GPU)

@@ -32,6 +32,18 @@ std::string frame_name(const std::string& destination, std::size_t k, std::size_
     std::snprintf(tag, sizeof tag, "_%05zu", k);
     return dot == std::string::npos ? destination + tag : destination.substr(0, dot) + tag + destination.substr(dot);
 }
+
+std::string png_name(const std::string& vti) {
+    const auto dot = vti.rfind('.');
+    const auto slash = vti.rfind('/');
+    const bool has_ext = dot != std::string::npos && (slash == std::string::npos || dot > slash);
+    return (has_ext ? vti.substr(0, dot) : vti) + ".png";
+}
+
+void write_frame(const object2d& img, const std::string& name) {
+    img.export_to_vti(name);
+    if (app::instance().config.png) img.export_to_png(png_name(name));
+}
 }  // namespace
 
 int main(int argc, char** argv) try {
@@ -47,7 +59,7 @@ int main(int argc, char** argv) try {
                 px[(static_cast<size_t>(y) * w + x) * 2 + 1] = static_cast<float>(x + 100 * y) + 0.5f;
             }
         px[(5 * w + 7) * 2] = px[(5 * w + 7) * 2 + 1] = std::numeric_limits<float>::quiet_NaN();
-        object2d(px, w, h).export_to_vti(config.selftest_vti);
+        write_frame(object2d(px, w, h), config.selftest_vti);
         return 0;
     }
 
@@ -174,7 +186,7 @@ int main(int argc, char** argv) try {
     t2 = timestamp();
     std::cout << "Ray-tracing completed in " << ms_between(t1, t2) << " ms. " << std::endl;  // main.cpp:131-135
 
-    if (config.bench == 0) result.export_to_vti(frame_name(config.destination, 0, config.frames));
+    if (config.bench == 0) write_frame(result, frame_name(config.destination, 0, config.frames));
     if (config.print_stats) {
         const c5_stats st = base_plane.stats();
         std::cout << "GPU frame: " << st.ms_total << " ms (transform " << st.ms_transform << ", records " << st.ms_records
@@ -209,7 +221,7 @@ int main(int argc, char** argv) try {
         const pending_frame f = in_flight.front();
         in_flight.pop_front();
         object2d img = f.p->trace_rays(tetra_value::alpha, tetra_value::Q);
-        if (write) img.export_to_vti(frame_name(config.destination, f.k, config.frames));
+        if (write) write_frame(img, frame_name(config.destination, f.k, config.frames));
     };
     if (config.bench == 0) {
         for (std::size_t k = 1; k < config.frames; ++k) {

@@ -87,6 +87,13 @@ std::shared_ptr<float> image_pool::take() {
     });
 }
 
+void object2d::export_to_png(const std::string& filename) const {
+    const render_config& cfg = app::instance().config;
+    double lo = cfg.png_lo, hi = cfg.png_hi;
+    if (!cfg.png_fixed_range) colour_range(_pixels.get(), static_cast<int>(_res_x), static_cast<int>(_res_y), cfg.png_channel, &lo, &hi);
+    write_png(filename, _pixels.get(), static_cast<int>(_res_x), static_cast<int>(_res_y), cfg.png_channel, lo, hi);
+}
+
 void object2d::export_to_vti(const std::string& filename) const {
     write_vti(filename, _pixels.get(), static_cast<int>(_res_x), static_cast<int>(_res_y),
               !app::instance().config.raw_vti);

@@ -38,6 +38,8 @@ public:
     object2d(std::shared_ptr<float> pinned, std::size_t res_x, std::size_t res_y)
         : _pixels(std::move(pinned)), _res_x(res_x), _res_y(res_y) {}
     void export_to_vti(const std::string& filename) const;  // object2d.cpp:7-29
+    // colour-mapped PNG of one channel over [lo, hi]; lo == hi == 0 and !fixed: the channel's own finite range
+    void export_to_png(const std::string& filename) const;
     float at(std::size_t x, std::size_t y, std::size_t channel) const { return _pixels.get()[(y * _res_x + x) * 2 + channel]; }
     std::size_t res_x() const { return _res_x; }
     std::size_t res_y() const { return _res_y; }

@@ -2,6 +2,8 @@
 
 #include <algorithm>
 #include <cctype>
+#include <cmath>
+#include <limits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -410,5 +412,221 @@ void write_vti(const std::string& path, const float* image, int res_x, int res_y
         f.write(text_buf.data(), static_cast<std::streamsize>(text_len));
     }
     f << "\n  </AppendedData>\n</VTKFile>\n";
+    if (!f) throw std::runtime_error("error while writing '" + path + "'");
+}
+
+// ------------------------------------------------------------------------------------------
+// Colour-mapped PNG of one channel: what utility/screen.py asks ParaView for, frame by frame
+// (ColorBy(('POINTS', 'ImageScalars', 'Y')) + SaveScreenshot, screen.py:11-14), without ParaView.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+// "Cool to Warm": ParaView's default colour map, three control points joined in Moreland's diverging
+// (Msh) colour space.  Restated from the published construction (K. Moreland, "Diverging Color Maps for
+// Scientific Visualization", 2009, section 5); there is no ParaView here to compare rendered pixels with.
+struct msh_t { double M, s, h; };
+constexpr double PI_3 = 3.14159265358979323846 / 3.0;
+
+double srgb_to_linear(double c) { return c > 0.04045 ? std::pow((c + 0.055) / 1.055, 2.4) : c / 12.92; }
+double linear_to_srgb(double c) { return c > 0.0031308 ? 1.055 * std::pow(c, 1.0 / 2.4) - 0.055 : 12.92 * c; }
+constexpr double kWhite[3] = {0.9505, 1.0, 1.0890};  // D65
+double lab_f(double t) { return t > 0.008856 ? std::cbrt(t) : 7.787 * t + 16.0 / 116.0; }
+double lab_f_inv(double t) { return t > 0.20689 ? t * t * t : (t - 16.0 / 116.0) / 7.787; }
+
+msh_t rgb_to_msh(const double rgb[3]) {
+    const double r = srgb_to_linear(rgb[0]), g = srgb_to_linear(rgb[1]), b = srgb_to_linear(rgb[2]);
+    const double X = 0.4124 * r + 0.3576 * g + 0.1805 * b;
+    const double Y = 0.2126 * r + 0.7152 * g + 0.0722 * b;
+    const double Z = 0.0193 * r + 0.1192 * g + 0.9505 * b;
+    const double fx = lab_f(X / kWhite[0]), fy = lab_f(Y / kWhite[1]), fz = lab_f(Z / kWhite[2]);
+    const double L = 116.0 * fy - 16.0, a = 500.0 * (fx - fy), bb = 200.0 * (fy - fz);
+    msh_t m;
+    m.M = std::sqrt(L * L + a * a + bb * bb);
+    m.s = m.M > 0.001 ? std::acos(L / m.M) : 0.0;
+    m.h = m.s > 0.001 ? std::atan2(bb, a) : 0.0;
+    return m;
+}
+void msh_to_rgb(const msh_t& m, double rgb[3]) {
+    const double L = m.M * std::cos(m.s), a = m.M * std::sin(m.s) * std::cos(m.h), b = m.M * std::sin(m.s) * std::sin(m.h);
+    const double fy = (L + 16.0) / 116.0, fx = a / 500.0 + fy, fz = fy - b / 200.0;
+    const double X = kWhite[0] * lab_f_inv(fx), Y = kWhite[1] * lab_f_inv(fy), Z = kWhite[2] * lab_f_inv(fz);
+    const double r = 3.2406 * X - 1.5372 * Y - 0.4986 * Z;
+    const double g = -0.9689 * X + 1.8758 * Y + 0.0415 * Z;
+    const double bl = 0.0557 * X - 0.2040 * Y + 1.0570 * Z;
+    const double lin[3] = {r, g, bl};
+    for (int k = 0; k < 3; ++k) rgb[k] = std::min(1.0, std::max(0.0, linear_to_srgb(std::max(0.0, lin[k]))));
+}
+// hue an unsaturated end takes so that the path towards the saturated end does not swing through other hues
+double adjust_hue(const msh_t& saturated, double M_unsaturated) {
+    if (saturated.M >= M_unsaturated - 0.1) return saturated.h;
+    const double spin = saturated.s * std::sqrt(M_unsaturated * M_unsaturated - saturated.M * saturated.M) /
+                        (saturated.M * std::sin(saturated.s));
+    return saturated.h > -PI_3 ? saturated.h + spin : saturated.h - spin;
+}
+void diverging_between(const double rgb1[3], const double rgb2[3], double t, double out[3]) {
+    msh_t a = rgb_to_msh(rgb1), b = rgb_to_msh(rgb2);
+    double dh = std::fabs(a.h - b.h);
+    if (dh > 3.14159265358979323846) dh = 2 * 3.14159265358979323846 - dh;
+    if (a.s > 0.05 && b.s > 0.05 && dh > PI_3) {  // two saturated ends: pass through white
+        const double mid = std::max(std::max(a.M, b.M), 88.0);
+        if (t < 0.5) { b = {mid, 0.0, 0.0}; t *= 2.0; }
+        else { a = {mid, 0.0, 0.0}; t = 2.0 * t - 1.0; }
+    }
+    if (a.s < 0.05 && b.s > 0.05) a.h = adjust_hue(b, a.M);
+    else if (b.s < 0.05 && a.s > 0.05) b.h = adjust_hue(a, b.M);
+    const msh_t m{(1 - t) * a.M + t * b.M, (1 - t) * a.s + t * b.s, (1 - t) * a.h + t * b.h};
+    msh_to_rgb(m, out);
+}
+
+struct colour_table {
+    unsigned char rgb[256][3];
+    colour_table() {
+        const double cool[3] = {0.23137254902, 0.298039215686, 0.752941176471};
+        const double mid[3] = {0.865, 0.865, 0.865};
+        const double warm[3] = {0.705882352941, 0.0156862745098, 0.149019607843};
+        for (int k = 0; k < 256; ++k) {
+            const double t = k / 255.0;
+            double c[3];
+            if (t < 0.5) diverging_between(cool, mid, 2.0 * t, c);
+            else diverging_between(mid, warm, 2.0 * t - 1.0, c);
+            for (int j = 0; j < 3; ++j) rgb[k][j] = static_cast<unsigned char>(std::lround(c[j] * 255.0));
+        }
+    }
+};
+
+void put_be32(unsigned char* p, uint32_t v) {
+    p[0] = static_cast<unsigned char>(v >> 24);
+    p[1] = static_cast<unsigned char>(v >> 16);
+    p[2] = static_cast<unsigned char>(v >> 8);
+    p[3] = static_cast<unsigned char>(v);
+}
+void png_chunk(std::ofstream& f, const char type[4], const unsigned char* data, size_t n) {
+    unsigned char head[8];
+    put_be32(head, static_cast<uint32_t>(n));
+    std::memcpy(head + 4, type, 4);
+    f.write(reinterpret_cast<const char*>(head), 8);
+    if (n) f.write(reinterpret_cast<const char*>(data), static_cast<std::streamsize>(n));
+    uLong crc = crc32(0L, reinterpret_cast<const Bytef*>(type), 4);
+    if (n) crc = crc32(crc, data, static_cast<uInt>(n));
+    unsigned char tail[4];
+    put_be32(tail, static_cast<uint32_t>(crc));
+    f.write(reinterpret_cast<const char*>(tail), 4);
+}
+
+}  // namespace
+
+void colour_range(const float* image, int res_x, int res_y, int channel, double* lo, double* hi) {
+    const int64_t n = static_cast<int64_t>(res_x) * res_y;
+    float mn = std::numeric_limits<float>::infinity(), mx = -std::numeric_limits<float>::infinity();
+#pragma omp parallel for schedule(static) reduction(min : mn) reduction(max : mx) num_threads(writer_threads())
+    for (int64_t k = 0; k < n; ++k) {
+        const float v = image[2 * k + channel];
+        if (std::isfinite(v)) {
+            mn = std::min(mn, v);
+            mx = std::max(mx, v);
+        }
+    }
+    if (!(mn <= mx)) mn = mx = 0.f;  // no finite value at all
+    *lo = mn;
+    *hi = mx;
+}
+
+void write_png(const std::string& path, const float* image, int res_x, int res_y, int channel, double lo, double hi) {
+    static const colour_table table;
+    constexpr unsigned char kNan[3] = {255, 255, 0};  // ParaView's default NaN colour
+    if (res_x <= 0 || res_y <= 0 || channel < 0 || channel > 1) throw std::runtime_error("write_png: bad image shape");
+    const double scale = hi > lo ? 255.0 / (hi - lo) : 0.0;
+    // scanlines top to bottom = image rows res_y - 1 ... 0 (y points up in the reference's ParaView view);
+    // every scanline: filter byte 1 (Sub: each byte minus the one three to its left), then RGB
+    const size_t line = 1 + static_cast<size_t>(res_x) * 3;
+    static thread_local std::vector<unsigned char> raw_buf, packed_buf;
+    if (raw_buf.size() < line * static_cast<size_t>(res_y)) raw_buf.resize(line * static_cast<size_t>(res_y));
+    unsigned char* const raw = raw_buf.data();
+#pragma omp parallel for schedule(static) num_threads(writer_threads())
+    for (int s = 0; s < res_y; ++s) {
+        const float* src = image + static_cast<size_t>(res_y - 1 - s) * res_x * 2 + channel;
+        unsigned char* dst = raw + static_cast<size_t>(s) * line;
+        *dst++ = 1;
+        unsigned char left[3] = {0, 0, 0};
+        for (int x = 0; x < res_x; ++x) {
+            const float v = src[2 * static_cast<size_t>(x)];
+            const unsigned char* c = kNan;
+            if (v == v) {  // (+-inf clamp to the ends of the map)
+                const double t = (static_cast<double>(v) - lo) * scale;
+                c = table.rgb[static_cast<int>(std::lround(std::min(255.0, std::max(0.0, t))))];
+            }
+            for (int j = 0; j < 3; ++j) {
+                dst[j] = static_cast<unsigned char>(c[j] - left[j]);
+                left[j] = c[j];
+            }
+            dst += 3;
+        }
+    }
+    // one zlib stream out of independently deflated bands (each ends on a byte boundary with a full flush,
+    // the last with the final block), so that the bands are compressed side by side
+    const int bands = std::max(1, std::min(res_y / 16, 4 * writer_threads()));
+    std::vector<size_t> band_first(bands + 1);
+    for (int b = 0; b <= bands; ++b) band_first[b] = static_cast<size_t>(static_cast<int64_t>(res_y) * b / bands);
+    std::vector<uLong> bound(bands), used(bands, 0), adler(bands);
+    std::vector<size_t> at(bands + 1, 0);
+    for (int b = 0; b < bands; ++b) {
+        bound[b] = compressBound(static_cast<uLong>((band_first[b + 1] - band_first[b]) * line)) + 16;
+        at[b + 1] = at[b] + bound[b];
+    }
+    if (packed_buf.size() < at[bands]) packed_buf.resize(at[bands]);
+    unsigned char* const packed = packed_buf.data();
+    bool failed = false;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(writer_threads())
+    for (int b = 0; b < bands; ++b) {
+        const unsigned char* in = raw + band_first[b] * line;
+        const size_t n_in = (band_first[b + 1] - band_first[b]) * line;
+        z_stream z;
+        std::memset(&z, 0, sizeof z);
+        if (deflateInit2(&z, Z_BEST_SPEED, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+#pragma omp atomic write
+            failed = true;
+            continue;
+        }
+        z.next_in = const_cast<Bytef*>(in);
+        z.avail_in = static_cast<uInt>(n_in);
+        z.next_out = packed + at[b];
+        z.avail_out = static_cast<uInt>(bound[b]);
+        const int rc = deflate(&z, b + 1 == bands ? Z_FINISH : Z_FULL_FLUSH);
+        if ((b + 1 == bands && rc != Z_STREAM_END) || (b + 1 != bands && (rc != Z_OK || z.avail_in != 0))) {
+#pragma omp atomic write
+            failed = true;
+        }
+        used[b] = z.total_out;
+        deflateEnd(&z);
+        adler[b] = adler32(adler32(0L, Z_NULL, 0), in, static_cast<uInt>(n_in));
+    }
+    if (failed) throw std::runtime_error("zlib failed while writing '" + path + "'");
+    uLong check = adler[0];
+    for (int b = 1; b < bands; ++b) check = adler32_combine(check, adler[b], static_cast<z_off_t>((band_first[b + 1] - band_first[b]) * line));
+    size_t total = 2 + 4;
+    for (int b = 0; b < bands; ++b) total += used[b];
+    std::vector<unsigned char> idat(total);
+    idat[0] = 0x78;
+    idat[1] = 0x01;
+    size_t w = 2;
+    for (int b = 0; b < bands; ++b) {
+        std::memcpy(idat.data() + w, packed + at[b], used[b]);
+        w += used[b];
+    }
+    put_be32(idat.data() + w, static_cast<uint32_t>(check));
+
+    std::ofstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot write '" + path + "'");
+    static const unsigned char magic[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    f.write(reinterpret_cast<const char*>(magic), 8);
+    unsigned char ihdr[13];
+    put_be32(ihdr, static_cast<uint32_t>(res_x));
+    put_be32(ihdr + 4, static_cast<uint32_t>(res_y));
+    ihdr[8] = 8;   // bits per sample
+    ihdr[9] = 2;   // truecolour
+    ihdr[10] = ihdr[11] = ihdr[12] = 0;
+    png_chunk(f, "IHDR", ihdr, sizeof ihdr);
+    png_chunk(f, "IDAT", idat.data(), idat.size());
+    png_chunk(f, "IEND", nullptr, 0);
     if (!f) throw std::runtime_error("error while writing '" + path + "'");
 }

@@ -29,3 +29,10 @@ vtk_grid read_legacy_vtk(const std::string& path);
 //                       vtkXMLImageDataWriter uses by default, i.e. what the reference writes;
 //   compressed = false: appended raw data (larger, fastest to write).
 void write_vti(const std::string& path, const float* image, int res_x, int res_y, bool compressed = true);
+
+// Colour-mapped 8-bit RGB PNG of one channel (0: tau, 1: I — the component utility/screen.py colours by),
+// "Cool to Warm" between lo and hi, NaN pixels yellow (ParaView's defaults); scanlines from the top image row
+// (largest y) down.  colour_range: smallest and largest finite value of the channel (ParaView's rescale to
+// the data range on load).
+void colour_range(const float* image, int res_x, int res_y, int channel, double* lo, double* hi);
+void write_png(const std::string& path, const float* image, int res_x, int res_y, int channel, double lo, double hi);

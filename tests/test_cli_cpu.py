@@ -141,3 +141,45 @@ def test_vti_writer_round_trip(tmp_path, raw):
     assert np.array_equal(img, want, equal_nan=True)
     head = out.read_bytes()[:600].decode(errors="replace")
     assert ("vtkZLibDataCompressor" in head) == (not raw)
+
+
+# K. Moreland's published 33-entry table of the "Cool to Warm" map (CoolWarmUChar33), scalar k / 32 -> RGB
+COOL_TO_WARM_33 = [(59, 76, 192), (68, 90, 204), (77, 104, 215), (87, 117, 225), (98, 130, 234), (108, 142, 241),
+                   (119, 154, 247), (130, 165, 251), (141, 176, 254), (152, 185, 255), (163, 194, 255), (174, 201, 253),
+                   (184, 208, 249), (194, 213, 244), (204, 217, 238), (213, 219, 230), (221, 221, 221), (229, 216, 209),
+                   (236, 211, 197), (241, 204, 185), (245, 196, 173), (247, 187, 160), (247, 177, 148), (247, 166, 135),
+                   (244, 154, 123), (241, 141, 111), (236, 127, 99), (229, 112, 88), (222, 96, 77), (213, 80, 66),
+                   (203, 62, 56), (192, 40, 47), (180, 4, 38)]
+
+
+def test_png_writer_colour_map_orientation_and_nan(tmp_path):
+    """`--png`: what utility/screen.py gets from ParaView per frame (component 'Y' coloured with the default map),
+    written by the binary itself.  The map is checked against the published 33-entry table of Cool to Warm (the
+    256-entry table of the writer may round a component one step differently), NaN pixels are ParaView's yellow, the
+    top scanline is the image's last row (y up), and without --png_range a frame is mapped over its own finite range."""
+    from course5_amd import vtkio
+    out = tmp_path / "t.vti"
+    r = run("--selftest_vti", str(out), "--png", "--png_channel", "0", "--png_range", "0,32")
+    assert r.returncode == 0, r.stderr
+    rgb = vtkio.read_png(str(tmp_path / "t.png")).astype(int)
+    assert rgb.shape == (32, 48, 3)
+    bottom = rgb[-1]  # image row 0: values 0 ... 47
+    assert np.abs(bottom[:33] - np.array(COOL_TO_WARM_33)).max() <= 1
+    assert (bottom[33:] == np.array(COOL_TO_WARM_33[-1])).all()      # above the range: clamped to the warm end
+    assert tuple(rgb[31 - 5, 7]) == (255, 255, 0)                     # the NaN pixel (row 5, column 7)
+    assert (rgb[0] == np.array(COOL_TO_WARM_33[-1])).all()            # image row 31: values 3100 ...
+
+    r = run("--selftest_vti", str(out), "--png")  # channel 1 over its own range 0.5 ... 3147.5
+    assert r.returncode == 0, r.stderr
+    rgb = vtkio.read_png(str(tmp_path / "t.png")).astype(int)
+    assert tuple(rgb[-1, 0]) == COOL_TO_WARM_33[0] and tuple(rgb[0, -1]) == COOL_TO_WARM_33[-1]
+    img, _ = vtkio.read_vti(str(out))
+    v = img[..., 1]
+    t = (v - np.nanmin(v)) / (np.nanmax(v) - np.nanmin(v))
+    grey = np.abs(t - 0.5) < 0.01                                    # the middle of the range is the map's grey
+    assert grey.any() and (np.abs(rgb[::-1][grey] - 221) <= 4).all()
+
+
+def test_png_options_are_validated():
+    assert run("--selftest_vti", "/dev/null", "--png_channel", "2").returncode == 1
+    assert run("--selftest_vti", "/dev/null", "--png_range", "5").returncode == 1

@@ -224,3 +224,29 @@ def test_course_sweep_survives_a_starved_entry_pool(tmp_path):
             calm, _ = vtkio.read_vti(str(tmp_path / f"calm_{k:05d}.vti"))
             two, _ = vtkio.read_vti(str(tmp_path / f"two_{k:05d}.vti"))
             assert np.array_equal(calm, two), k
+
+
+def test_course_sweep_writes_colour_mapped_frames(tmp_path):
+    """f-3: the sweep driver also writes what utility/screen.py makes per frame — a PNG of channel 'Y' in ParaView's
+    default map — so that rotate_traces.py's 1500 process launches + pvpython calls become one run.  The PNG of a
+    frame is its .vti mapped: NaN (solid) pixels yellow, everything else the colour of its intensity over the
+    fixed range, rows top down."""
+    xyz, cells, a, q = mg.workload("g2")
+    src = tmp_path / "g2.vtk"
+    mg.write_vtk_ascii(str(src), xyz, cells, a, q)
+    _run(["-f", src, "-d", tmp_path / "f.vti", "-x", 300, "-y", 225, "-X", 0.1, "-Y", 0.07, "--frames", 3, "--sweep", "D",
+          "--sweep_step", 0.1, "--png", "--png_range", "0,0.5", "-j4"])
+    for k in range(3):
+        img, _ = vtkio.read_vti(str(tmp_path / f"f_{k:05d}.vti"))
+        rgb = vtkio.read_png(str(tmp_path / f"f_{k:05d}.png"))[::-1].astype(int)  # back to image rows
+        assert rgb.shape == (225, 300, 3)
+        nan = np.isnan(img[..., 1])
+        assert nan.sum() > 100 and (rgb[nan] == np.array([255, 255, 0])).all()
+        empty = (~nan) & (img[..., 1] == 0)
+        assert empty.any() and (rgb[empty] == np.array([59, 76, 192])).all()      # the cool end
+        lit = (~nan) & (img[..., 1] > 0.01)
+        assert lit.sum() > 1000 and (rgb[lit] != np.array([59, 76, 192])).any(axis=-1).all()
+        # brighter pixels are never bluer: the red component grows with the value up to the middle of the map
+        lower_half = (~nan) & (img[..., 1] < 0.25)
+        order = np.argsort(img[..., 1][lower_half], kind="stable")
+        assert (np.diff(rgb[..., 0][lower_half][order]) >= 0).all()
