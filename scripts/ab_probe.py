@@ -1,0 +1,45 @@
+"""A/B of two builds of the library in ONE process, runs interleaved (A B A B ...), so that clock and temperature
+drift hits both alike.  usage: ab_probe.py libA.so libB.so [precision] [rounds] [workload]"""
+import sys
+import torch
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+from course5_amd import capi, meshgen as mg  # noqa: E402
+
+paths = sys.argv[1:3]
+precision = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+workload = sys.argv[5] if len(sys.argv) > 5 else "c3"
+res = {"c3": (2400, 1800), "c2": (1200, 900)}[workload]
+xyz, cells, alpha, q = mg.workload(workload)
+out = torch.zeros((res[1], res[0], 2), dtype=torch.float32, device="cuda:0")
+ctxs = []
+for p in paths:
+    capi._lib = None
+    capi.LIB_PATH = p
+    ctx = capi.Context(0)
+    ctx.upload_grid(xyz, cells, alpha, q)
+    ctx.set_image(res[0], res[1], mg.REFERENCE_BOUNDS)
+    ctx.set_view(mg.view_rotations(**mg.BENCH_VIEW))
+    ctx.set_option("stage_timing", 0)
+    ctx.set_option("precision", precision)
+    ctxs.append(ctx)
+
+
+def run(ctx, n):
+    for _ in range(n):
+        ctx.render_device(out.data_ptr())
+    ctx.synchronize()
+    return ctx.walk_kernel_ms(reset=True)[0]
+
+
+for ctx in ctxs:
+    run(ctx, 300)
+tot = [0.0, 0.0]
+for r in range(rounds):
+    line = []
+    for k, ctx in enumerate(ctxs):
+        ms = run(ctx, 300)
+        tot[k] += ms
+        line.append("%s %.4f" % (paths[k].split("/")[-1], ms))
+    print("round", r, " | ".join(line), flush=True)
+print("precision", precision, "mean walk ms:", " | ".join("%s %.4f" % (paths[k].split("/")[-1], tot[k] / rounds) for k in range(2)))
