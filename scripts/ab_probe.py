@@ -1,14 +1,15 @@
 """A/B of two builds of the library in ONE process, runs interleaved (A B A B ...), so that clock and temperature
-drift hits both alike.  usage: ab_probe.py libA.so libB.so [precision] [rounds] [workload]"""
+drift hits all alike.  usage: ab_probe.py libA.so libB.so [libC.so ...] [precision] [rounds] [workload]"""
 import sys
 import torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from course5_amd import capi, meshgen as mg  # noqa: E402
 
-paths = sys.argv[1:3]
-precision = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 5
-workload = sys.argv[5] if len(sys.argv) > 5 else "c3"
+paths = [a for a in sys.argv[1:] if a.endswith(".so")]
+rest = [a for a in sys.argv[1:] if not a.endswith(".so")]
+precision = int(rest[0]) if len(rest) > 0 else 0
+rounds = int(rest[1]) if len(rest) > 1 else 5
+workload = rest[2] if len(rest) > 2 else "c3"
 res = {"c3": (2400, 1800), "c2": (1200, 900)}[workload]
 xyz, cells, alpha, q = mg.workload(workload)
 out = torch.zeros((res[1], res[0], 2), dtype=torch.float32, device="cuda:0")
@@ -34,7 +35,7 @@ def run(ctx, n):
 
 for ctx in ctxs:
     run(ctx, 300)
-tot = [0.0, 0.0]
+tot = [0.0] * len(paths)
 for r in range(rounds):
     line = []
     for k, ctx in enumerate(ctxs):
@@ -42,4 +43,4 @@ for r in range(rounds):
         tot[k] += ms
         line.append("%s %.4f" % (paths[k].split("/")[-1], ms))
     print("round", r, " | ".join(line), flush=True)
-print("precision", precision, "mean walk ms:", " | ".join("%s %.4f" % (paths[k].split("/")[-1], tot[k] / rounds) for k in range(2)))
+print("precision", precision, "mean walk ms:", " | ".join("%s %.4f" % (paths[k].split("/")[-1], tot[k] / rounds) for k in range(len(paths))))
