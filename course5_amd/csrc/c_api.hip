@@ -49,6 +49,11 @@ struct DeviceBuffer {
     }
 };
 
+// where a frame's CellOptics start inside its record allocation
+inline size_t optics_offset(int64_t n_cells) {
+    return (static_cast<size_t>(n_cells) * sizeof(c5::CellRecord) + 128 + 255) & ~static_cast<size_t>(255);
+}
+
 struct Solid {
     int64_t n_tets = 0;      // as given
     int64_t n_points = 0;    // unique points
@@ -129,7 +134,7 @@ struct c5_context {
     double steep_ratio = 128.0;  // "precision" 1: cells whose fp32 plane terms exceed this many cell extents are evaluated in fp64
     int rays_per_lane = 1;  // "precision" 1 only: 2 = walk_composite_mixed2 (8 x 16 pixel tile per wavefront)
     int precision = 0;  // 0: fp64 walk, bit-faithful (default); 1: fp32 geometry + fp64 accumulators (walk_mixed.hip)
-    int lds_stage = 1;
+    int lds_stage = 2;
     int stage_timing = 1;
     int walk_timing = 1;
 
@@ -376,7 +381,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     g.q = ctx->q.as<double>();
     g.bface = ctx->bface.as<uint32_t>();
     g.rec = fs.rec.as<c5::CellRecord>();
-    g.opt = fs.opt.as<c5::CellOptics>();
+    g.opt = reinterpret_cast<c5::CellOptics*>(static_cast<char*>(fs.rec.ptr) + optics_offset(ctx->n_cells));
     // y band of the rows this context renders (one pixel of slack on both sides)
     if (im.n_local_rows > 0) {
         const int first = c5::global_row_of(im, 0), last = c5::global_row_of(im, im.n_local_rows - 1);
@@ -410,18 +415,19 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     const bool mixed = ctx->precision == 1 && c5::mixed_precision_fits(ctx->n_cells, im);
     if (mixed) {
         const size_t nc = static_cast<size_t>(ctx->n_cells);
-        if (fs.geo.bytes < nc * sizeof(c5::GeoRecord) + 64) {
+        // geometry and optics in ONE allocation, the optics behind the geometry: the walk's staging loads (LDS-DMA)
+        // reach both with one 32-bit offset from the geometry
+        const size_t opt32_at = (nc * sizeof(c5::GeoRecord) + 64 + 255) & ~static_cast<size_t>(255);
+        if (fs.geo.bytes < opt32_at + nc * sizeof(c5::OptRecord) + 256) {
             // records of cells outside a context's row band are never rebuilt: whatever they hold must be a valid
             // record (zeros: neighbour ids inside the grid)
-            C5_HIP(ctx, fs.geo.ensure(nc * sizeof(c5::GeoRecord) + 64));
-            C5_HIP(ctx, fs.opt32.ensure(nc * sizeof(c5::OptRecord) + 16));
+            C5_HIP(ctx, fs.geo.ensure(opt32_at + nc * sizeof(c5::OptRecord) + 256));
             C5_HIP(ctx, fs.z0.ensure(nc * sizeof(float) + 4));
             C5_HIP(ctx, hipMemsetAsync(fs.geo.ptr, 0, fs.geo.bytes, s));
-            C5_HIP(ctx, hipMemsetAsync(fs.opt32.ptr, 0, fs.opt32.bytes, s));
             C5_HIP(ctx, hipMemsetAsync(fs.z0.ptr, 0, fs.z0.bytes, s));
         }
         g.geo = fs.geo.as<c5::GeoRecord>();
-        g.opt32 = fs.opt32.as<c5::OptRecord>();
+        g.opt32 = reinterpret_cast<c5::OptRecord*>(static_cast<char*>(fs.geo.ptr) + opt32_at);
         g.z0 = fs.z0.as<float>();
         c5::launch_build_records_mixed(s, g, im, ctx->xtab.as<double>(), ctx->ytab.as<double>(), ctx->alpha_limit, ctx->order, ctx->steep_ratio);
     } else if (!(ctx->fuse_setup && !side && g.n_cells > 0)) {
@@ -481,7 +487,8 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     wp.band_rows = ctx->band_rows;
     wp.order = ctx->order;
     // walk_composite_lds addresses the records by 32-bit byte offsets: n_cells * 128 must fit
-    wp.lds_stage = (ctx->lds_stage && ctx->n_cells < (int64_t{1} << 25)) ? 1 : 0;
+    // (2: LDS-DMA staging — ids times 128 through a 24-bit multiply, optics within 32 bits of the records)
+    wp.lds_stage = (ctx->lds_stage && ctx->n_cells < (int64_t{1} << 25)) ? ((ctx->lds_stage == 2 && ctx->n_cells < (int64_t{1} << 24)) ? 2 : 1) : 0;
     wp.counters = fs.counters.as<c5::FrameCounters>();
     wp.row_cost = nullptr;
     wp.sticky = ctx->sticky.as<unsigned>();
@@ -838,12 +845,12 @@ int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int3
         C5_HIP(ctx, fs.vx.ensure(pb ? pb : 8));
         C5_HIP(ctx, fs.vy.ensure(pb ? pb : 8));
         C5_HIP(ctx, fs.vz.ensure(pb ? pb : 8));
-        C5_HIP(ctx, fs.rec.ensure(cb * sizeof(c5::CellRecord) + 128));
-        C5_HIP(ctx, fs.opt.ensure(cb * sizeof(c5::CellOptics) + 32));
+        // records and optics in ONE allocation, the optics behind the records (optics_offset): the staging loads of
+        // walk_composite_lds<.., DMA> reach both with one 32-bit offset from the records
+        C5_HIP(ctx, fs.rec.ensure(optics_offset(n_cells) + cb * sizeof(c5::CellOptics) + 256));
         // records of cells outside a context's row band are never rebuilt; keep whatever they hold a
         // valid record (neighbour ids inside the grid) from the start
         C5_HIP(ctx, hipMemset(fs.rec.ptr, 0, fs.rec.bytes));
-        C5_HIP(ctx, hipMemset(fs.opt.ptr, 0, fs.opt.bytes));
         fs.geo.release();  // "precision" 1 records of the old grid: rebuilt (and zeroed) on first use
         fs.opt32.release();
         fs.z0.release();
@@ -1071,7 +1078,7 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
         if (value != 0 && value != 1) return fail(ctx, C5_ERR_INVALID, "algorithm must be 0 (walk) or 1 (bin_sort_resolve)");
         ctx->algorithm = static_cast<int>(value);
     } else if (n == "lds_stage") {
-        ctx->lds_stage = static_cast<int>(value) != 0;
+        ctx->lds_stage = static_cast<int>(value) < 0 ? 0 : (static_cast<int>(value) > 2 ? 2 : static_cast<int>(value));
     } else if (n == "integration") {
         ctx->order = static_cast<int>(value) != 0;
     } else if (n == "rays_per_lane") {

@@ -480,11 +480,30 @@ __device__ unsigned long long g_walk_stamps[16];
     } while (0)
 #endif
 
-template <int TILE, int ORDER>
-__global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkParams P) {
+// DMA = true (option "lds_stage" 2): the staging loads write LDS themselves (global_load_lds_dwordx4: destination =
+// wave-uniform base + 16 * lane, no vector register in between, no ds_write_b128 — a 16-byte LDS store costs 13
+// LDS cycles per wave-instruction, a step's three as much as its ten reads).  A pass of 64 lanes fills 64
+// consecutive 16-byte units of the wavefront's staging area, i.e. units 64 j ... 64 j + 63 of the same
+// slot * 11 + piece image the register path writes: lane -> (slot, piece) differs from pass to pass (11 does not
+// divide 64), so every lane keeps, per pass, where its slot's cell id is posted and what its piece's source
+// offset is; pad units and slots beyond the staged ones are masked off.  Records and optics are fetched by the
+// SAME instruction (pieces 0-7: rec + id * 128, pieces 8-9: opt + id * 32): the host allocates opt behind rec, so
+// that one 32-bit offset from rec reaches both.
+#ifndef C5_DMA_WAVES
+#define C5_DMA_WAVES 7
+#endif
+// 1 (DMA kernel only): a step's emission/absorption is integrated at once, behind its geometry — nothing carried to
+// the next iteration, ten registers fewer — instead of in the shadow of the next step's loads
+#ifndef C5_EMIT_NOW
+#define C5_EMIT_NOW 0
+#endif
+using LdsInts = const __attribute__((address_space(3))) int*;
+template <int TILE, int ORDER, bool DMA = false>
+__global__ __launch_bounds__(256, DMA ? C5_DMA_WAVES : C5_WALK_WAVES) void walk_composite_lds(WalkParams P) {
     using TS = TileShape<TILE>;
     constexpr int TW = TS::WW * TS::GX, TH = TS::WH * TS::GY;
     constexpr bool kUp = (ORDER == 0);
+    constexpr bool kEmitNow = DMA && C5_EMIT_NOW != 0;
     __shared__ V2 s_stage[4][kStageSlots * kSlotStride];
     // per wavefront: leader tables of kBuckets1 and 64 buckets + the cell id of every slot
     __shared__ int s_elect[4][kBuckets1 + 128];
@@ -595,6 +614,24 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
     const int sub4 = sub << 2, so4 = so << 2;  // ds_bpermute byte addresses of slot `sub` / `so`
     V2* const put_rec = my_stage + sub * kSlotStride + piece;         // + 8 * pass * kSlotStride
     V2* const put_opt = my_stage + so * kSlotStride + 8 + (lane & 1);
+    // DMA: per pass, the LDS address of this lane's slot id (beyond every limit where the lane has nothing to
+    // fetch), log2 of the bytes per cell of the array its piece comes from and the piece's offset from P.rec
+    // DMA: a pass stages kDmaSlots = 5 whole slots (55 lanes; the last nine idle), so that a lane fetches the same
+    // piece of the same slot-within-the-pass in every pass: three registers hold where that slot's cell id is
+    // posted (beyond every limit where the lane has nothing to fetch), log2 of the bytes per cell of the array the
+    // piece comes from and the piece's offset from P.rec.  Pass j: slots 5 j ... 5 j + 4, LDS units from 55 j.
+    constexpr int kDmaSlots = 64 / kSlotStride;
+    constexpr int kDmaPasses = (kStageSlots + kDmaSlots - 1) / kDmaSlots;
+    uint32_t dma_id_at = 0, dma_pitch = 0, dma_off = 0;
+    if (DMA) {
+        const uint32_t opt_delta = static_cast<uint32_t>(opt_bytes - rec_bytes);
+        const uint32_t ids_at = (uint32_t)(uintptr_t)(LdsInts)(my_elect + kBuckets1 + 64);  // LDS byte address
+        const int s_ = lane / kSlotStride, pc = lane - s_ * kSlotStride;
+        const bool has = s_ < kDmaSlots && pc < 10;
+        dma_id_at = has ? ids_at + 4u * static_cast<uint32_t>(s_) : 0xFFFFF000u;
+        dma_pitch = pc < 8 ? 7u : 5u;
+        dma_off = pc < 8 ? 16u * static_cast<uint32_t>(pc) : opt_delta + 16u * static_cast<uint32_t>(pc - 8);
+    }
 
     // A lane steps in every iteration from its start to its end (re-entry takes no extra iteration), so
     // the wave-uniform iteration count IS the step count of every lane still walking: the guard
@@ -701,21 +738,37 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
 #pragma clang diagnostic ignored "-Wsometimes-uninitialized"
 #pragma clang diagnostic ignored "-Wconditional-uninitialized"
         V2 stage_r[kPasses];  // a skipped pass leaves its register undefined; it is never stored either
+        V2 stage_o0;
 #pragma clang diagnostic pop
+        if (DMA) {
+            const uint32_t ids_end = (uint32_t)(uintptr_t)(LdsInts)(my_elect + kBuckets1 + 64) + 4u * static_cast<uint32_t>(n_staged);
 #pragma unroll
-        for (int pass = 0; pass < kPasses; ++pass) {  // fully unrolled: stage_r[] stays in registers
-            if (pass == 0 || 8 * pass < n_staged) {
-                const uint32_t id_ = static_cast<uint32_t>(
-                    kElectLeaders ? my_elect[kBuckets1 + 64 + 8 * pass + sub] : __builtin_amdgcn_ds_bpermute(sub4 + 32 * pass, id_of_lane));
-                stage_r[pass] = *reinterpret_cast<const V2*>(rec_bytes + ((id_ << 7) | rec_piece_off));
+            for (int j = 0; j < kDmaPasses; ++j) {
+                if (j == 0 || kDmaSlots * j < n_staged) {  // wave-uniform: does the pass reach a staged slot at all
+                    if (dma_id_at < ids_end - 4u * kDmaSlots * j) {  // this lane's slot 5 j + s is staged (idle lanes: never)
+                        const uint32_t id_ = static_cast<uint32_t>(((LdsInts)(uintptr_t)dma_id_at)[kDmaSlots * j]);
+                        const uint32_t off = (id_ << dma_pitch) + dma_off;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rec_bytes + off),
+                                                         (__attribute__((address_space(3))) void*)(my_stage + kDmaSlots * kSlotStride * j), 16, 0, 0);
+                    }
+                }
             }
+        } else {
+#pragma unroll
+            for (int pass = 0; pass < kPasses; ++pass) {  // fully unrolled: stage_r[] stays in registers
+                if (pass == 0 || 8 * pass < n_staged) {
+                    const uint32_t id_ = static_cast<uint32_t>(
+                        kElectLeaders ? my_elect[kBuckets1 + 64 + 8 * pass + sub] : __builtin_amdgcn_ds_bpermute(sub4 + 32 * pass, id_of_lane));
+                    stage_r[pass] = *reinterpret_cast<const V2*>(rec_bytes + ((id_ << 7) | rec_piece_off));
+                }
+            }
+            const uint32_t ido = static_cast<uint32_t>(kElectLeaders ? my_elect[kBuckets1 + 64 + so] : __builtin_amdgcn_ds_bpermute(so4, id_of_lane));
+            stage_o0 = *reinterpret_cast<const V2*>(opt_bytes + ((ido << 5) | opt_piece_off));
         }
-        const uint32_t ido = static_cast<uint32_t>(kElectLeaders ? my_elect[kBuckets1 + 64 + so] : __builtin_amdgcn_ds_bpermute(so4, id_of_lane));
-        const V2 stage_o0 = *reinterpret_cast<const V2*>(opt_bytes + ((ido << 5) | opt_piece_off));
         C5_STAMP(1);  // bpermutes landed, five loads issued
 
         // ... while they are in flight: emission/absorption of the step just taken
-        {
+        if (!kEmitNow) {
             // (wave-uniform choice of the exp: every pending lane's argument within (-1/8, 0] -> the short series)
             const bool big_arg = pend && !(pend_o0.y * pend_dz < -kSmallExpArg);
             const bool short_exp = __builtin_amdgcn_ballot_w64(big_arg) == 0ull;
@@ -736,10 +789,15 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
 
         // 3. park the pieces in LDS (the previous step's reads are long done: same wavefront, in order)
         __builtin_amdgcn_wave_barrier();
+        if (DMA) {
+            // nothing orders a ds_read behind this wavefront's own LDS-DMA but its vmcnt
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
 #pragma unroll
-        for (int pass = 0; pass < kPasses; ++pass)
-            if (sub < n_staged - 8 * pass) put_rec[8 * pass * kSlotStride] = stage_r[pass];
-        if (so < n_staged) *put_opt = stage_o0;
+            for (int pass = 0; pass < kPasses; ++pass)
+                if (sub < n_staged - 8 * pass) put_rec[8 * pass * kSlotStride] = stage_r[pass];
+            if (so < n_staged) *put_opt = stage_o0;
+        }
         __builtin_amdgcn_wave_barrier();
 #if C5_WALK_STAMPS
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -775,8 +833,18 @@ __global__ __launch_bounds__(256, C5_WALK_WAVES) void walk_composite_lds(WalkPar
             if (sg.contributes) {
                 ++n_seg;
                 tau = fma(sg.dz, pend_o0.x, tau);  // line.cpp:189 (unclamped alpha); order-independent, done now
-                pend = true;
-                pend_dz = sg.dz;
+                if (kEmitNow) {
+                    if (ORDER == 0) {
+                        if (pend_o0.y != 0.0) I = reference_emission_step<false>(I, pend_o0.y, pend_o1.y, pend_o1.x, sg.dz);
+                    } else if (T >= P.t_cutoff) {
+                        const double ex = exp_nonpositive(-pend_o0.y * sg.dz);
+                        I = fma(T * pend_o1.x, 1.0 - ex, I);
+                        T *= ex;
+                    }
+                } else {
+                    pend = true;
+                    pend_dz = sg.dz;
+                }
             }
             // an edge-on or flat slot forwards nothing (build_records), so the neighbour word alone
             // says whether the ray goes on inside the grid
@@ -896,7 +964,10 @@ static void launch_walk_t(hipStream_t s, const WalkParams& p) {
         blocks = 8ll * ((n_sb + 7) / 8) * S * S;
         WalkParams q = p;
         q.band_tiles = S;
-        hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, q);
+        if (p.lds_stage == 2)
+            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, q);
+        else
+            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, q);
         return;
     } else {
         // ~16 image rows per band (one row of workgroups), but never fewer than 16 bands (2 per XCD) on a short strip
@@ -910,13 +981,17 @@ static void launch_walk_t(hipStream_t s, const WalkParams& p) {
         blocks = 8ll * rounds * band * tiles_x;
         WalkParams q = p;
         q.band_tiles = band;
-        if (p.lds_stage)
+        if (p.lds_stage == 2)
+            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, q);
+        else if (p.lds_stage)
             hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, q);
         else
             hipLaunchKernelGGL((walk_composite<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, q);
         return;
     }
-    if (p.lds_stage)
+    if (p.lds_stage == 2)
+        hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, p);
+    else if (p.lds_stage)
         hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, p);
     else
         hipLaunchKernelGGL((walk_composite<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);

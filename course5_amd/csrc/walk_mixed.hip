@@ -28,7 +28,8 @@ namespace c5 {
 
 bool mixed_precision_fits(int64_t n_cells, const ImageParams& im) {
     // 32-bit byte offsets into the 64-byte records; the lattice origin holds 16 bits per axis
-    return n_cells < (int64_t{1} << 26) && im.res_x <= 65535 && im.res_y <= 65535;
+    // (ids shifted by 6 and the optics behind the geometry, both inside 32 bits: 2^25 cells)
+    return n_cells < (int64_t{1} << 25) && im.res_x <= 65535 && im.res_y <= 65535;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -212,10 +213,22 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) void w
     float pend_dz = 0.0f;
     V4F pend_opt = {0.0f, 0.0f, 0.0f, 0.0f};  // {alpha_raw, alpha_c, source, -}
 
-    const uint32_t geo_piece_off = static_cast<uint32_t>(lane & 3) * 16u;
-    const int gslot = lane >> 2;  // slot whose geometry piece this lane loads
-    V4F* const put_geo = my_stage + gslot * kMixStride + (lane & 3);
-    V4F* const put_opt = my_stage + (lane & 15) * kMixStride + 4;
+    // Staging by LDS-DMA (global_load_lds_dwordx4: destination = wave-uniform base + 16 * lane; no vector register in
+    // between, no ds_write_b128): a pass of 60 lanes fills twelve whole slots of five 16-byte units, so a lane
+    // fetches the same piece of the same slot-within-the-pass in both passes.  Three registers: where that slot's
+    // cell id is posted (beyond every limit for the four idle lanes), log2 of the bytes per cell of the array the
+    // piece comes from (pieces 0-3: GeoRecord, 4: OptRecord) and the piece's offset from P.geo.
+    constexpr int kDmaSlots = 64 / kMixStride;
+    constexpr int kDmaPasses = (kMixSlots + kDmaSlots - 1) / kDmaSlots;
+    using LdsInts = const __attribute__((address_space(3))) int*;
+    uint32_t dma_id_at, dma_pitch, dma_off;
+    {
+        const uint32_t ids_at = (uint32_t)(uintptr_t)(LdsInts)(my_elect + kMixBuckets + 64);  // LDS byte address
+        const int s_ = lane / kMixStride, pc = lane - s_ * kMixStride;
+        dma_id_at = s_ < kDmaSlots ? ids_at + 4u * static_cast<uint32_t>(s_) : 0xFFFFF000u;
+        dma_pitch = pc < 4 ? 6u : 4u;
+        dma_off = pc < 4 ? 16u * static_cast<uint32_t>(pc) : static_cast<uint32_t>(opt_bytes - geo_bytes);
+    }
 
     for (unsigned iter = 0;; ++iter) {
         const bool need = nb >= 0;
@@ -257,19 +270,20 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) void w
         __builtin_amdgcn_wave_barrier();
         const int n_staged = __builtin_amdgcn_readfirstlane(n_runs < kMixSlots ? n_runs : kMixSlots);
 
-        // 2. cooperative loads: 4 lanes x 16 B per GeoRecord (all sixteen slots in ONE instruction), lanes 0-15
-        //    one OptRecord each
-        const uint32_t idg = static_cast<uint32_t>(my_elect[kMixBuckets + 64 + gslot]);
-        const V4F stage_g = *reinterpret_cast<const V4F*>(geo_bytes + ((idg << 6) | geo_piece_off));
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wuninitialized"
-#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
-#pragma clang diagnostic ignored "-Wconditional-uninitialized"
-        V4F stage_o;  // lanes 16-63 leave it undefined; they never store it either
-#pragma clang diagnostic pop
-        if (lane < 16) {
-            const uint32_t ido = static_cast<uint32_t>(my_elect[kMixBuckets + 64 + lane]);
-            stage_o = *reinterpret_cast<const V4F*>(opt_bytes + (ido << 4));
+        // 2. cooperative loads, straight into the slots: pass j stages slots 12 j ... 12 j + 11 (LDS units from 60 j)
+        {
+            const uint32_t ids_end = (uint32_t)(uintptr_t)(LdsInts)(my_elect + kMixBuckets + 64) + 4u * static_cast<uint32_t>(n_staged);
+#pragma unroll
+            for (int j = 0; j < kDmaPasses; ++j) {
+                if (j == 0 || kDmaSlots * j < n_staged) {  // wave-uniform
+                    if (dma_id_at < ids_end - 4u * kDmaSlots * j) {  // this lane's slot 12 j + s is staged
+                        const uint32_t id_ = static_cast<uint32_t>(((LdsInts)(uintptr_t)dma_id_at)[kDmaSlots * j]);
+                        const uint32_t off = (id_ << dma_pitch) + dma_off;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(geo_bytes + off),
+                                                         (__attribute__((address_space(3))) void*)(my_stage + kDmaSlots * kMixStride * j), 16, 0, 0);
+                    }
+                }
+            }
         }
 
         // ... while they are in flight: emission / absorption of the step just taken.
@@ -301,10 +315,9 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) void w
             pend = false;
         }
 
-        // 3. park the pieces in LDS
+        // 3. the pieces have landed (nothing orders a ds_read behind this wavefront's own LDS-DMA but its vmcnt)
         __builtin_amdgcn_wave_barrier();
-        if (gslot < n_staged) *put_geo = stage_g;
-        if (lane < n_staged) *put_opt = stage_o;  // (n_staged <= 16)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
 
         // 4. every ray fetches its cell

@@ -164,8 +164,10 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  non-conforming cells like the reference does; c5_upload_grid selects it by itself
  *                  when a face is shared by more than two cells.  Needs ~24 B per ray-cell segment
  *                  and synchronises inside c5_render_device.
- *   "lds_stage"    1 (default): walk_composite_lds — per step a wavefront loads each distinct cell
- *                  record once and stages it through LDS; 0: every lane loads its own record.
+ *   "lds_stage"    2 (default): walk_composite_lds with LDS-DMA staging — per step a wavefront loads each distinct
+ *                  cell record once, straight into LDS (global_load_lds_dwordx4), and its rays read it from there;
+ *                  1: the same staged through vector registers (global_load + ds_write_b128; also what 2 falls
+ *                  back to beyond 2^24 cells); 0: every lane loads its own record.  Same results, bit for bit.
  *   "tile"         wavefront tile: 0 = 64x1 row tile, 1 = 16x4, 2 = 8x8 pixels (default).
  *   "xcd_mode"     how workgroups map to the 8 XCDs (blocks b and b + 8 share an L2): 2 (default): square
  *                  super-blocks of workgroups dealt round-robin; 1: bands of image rows; 0: row-major tiles.

@@ -1,5 +1,6 @@
 """A/B of two builds of the library in ONE process, runs interleaved (A B A B ...), so that clock and temperature
 drift hits all alike.  usage: ab_probe.py libA.so libB.so [libC.so ...] [precision] [rounds] [workload]"""
+import os
 import sys
 import torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
@@ -23,6 +24,9 @@ for p in paths:
     ctx.set_view(mg.view_rotations(**mg.BENCH_VIEW))
     ctx.set_option("stage_timing", 0)
     ctx.set_option("precision", precision)
+    for kv in os.environ.get("C5_OPTS", "").split(","):  # e.g. C5_OPTS=lds_stage=2,band_rows=64
+        if kv:
+            ctx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     ctxs.append(ctx)
 
 

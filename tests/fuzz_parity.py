@@ -14,7 +14,7 @@ from course5_amd import capi, meshgen as mg
 from oracle.pyoracle import Oracle
 
 # (lds_stage, integration, tile); the first one is the product default
-VARIANTS = ((1, 0, 2), (1, 0, 0), (1, 1, 2), (0, 0, 1), (1, 0, 1), (0, 1, 0), (1, 1, 1))
+VARIANTS = ((2, 0, 2), (1, 0, 0), (2, 1, 2), (0, 0, 1), (2, 0, 1), (0, 1, 0), (1, 1, 1), (2, 0, 0), (1, 0, 2), (2, 1, 1))
 
 
 def scene(seed):
@@ -71,7 +71,7 @@ def main():
                       f"S {st['segments']} vs {ref['segments']}, covered {st['covered_pixels']} vs {ref['covered']}, "
                       f"cells {len(cells)} res {res}", flush=True)
         # option "precision" 1 on the same scene: same bar for the image, the count may differ by grazing rays
-        ctx.set_option("lds_stage", 1); ctx.set_option("tile", 2)
+        ctx.set_option("lds_stage", 2); ctx.set_option("tile", 2)
         for order in (0, 1):
             ctx.set_option("integration", order); ctx.set_option("precision", 1)
             img = ctx.render(); st = ctx.stats()
@@ -88,7 +88,7 @@ def main():
         # cyclic row tiles and contiguous blocks, random world size and tile height, product-default kernel
         from course5_amd import sharding
         rng = np.random.default_rng(seed + 77)
-        ctx.set_option("lds_stage", 1); ctx.set_option("integration", 0); ctx.set_option("tile", 2)
+        ctx.set_option("lds_stage", 2); ctx.set_option("integration", 0); ctx.set_option("tile", 2)
         ctx.set_row_tiles(0, 0, 1)
         ctx.set_row_range(0, -1)
         full = ctx.render()

@@ -58,7 +58,7 @@ def test_random_scenes_match_the_oracle(gpu_ctx, oracle_port, block):
         tol = 1e-5 * np.maximum(np.abs(a), np.abs(b)) + 1e-6 * np.abs(b).max()
         assert int((np.abs(a - b) > tol).sum()) == 0, ("mixed", seed)
         assert abs(st["segments"] - ref["segments"]) <= max(3, ref["segments"] // 5000), ("mixed", seed)
-    gpu_ctx.set_option("lds_stage", 1)
+    gpu_ctx.set_option("lds_stage", 2)
     gpu_ctx.set_option("integration", 0)
     gpu_ctx.set_option("tile", 2)
     gpu_ctx.set_alpha_limit(2.5)

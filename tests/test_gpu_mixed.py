@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 def _mixed(gpu_ctx):
     for k in range(8):
         gpu_ctx.set_solid(k, np.zeros((0, 12)))
-    for name, v in (("tile", 2), ("integration", 0), ("lds_stage", 1), ("algorithm", 0), ("xcd_mode", 2), ("precision", 1)):
+    for name, v in (("tile", 2), ("integration", 0), ("lds_stage", 2), ("algorithm", 0), ("xcd_mode", 2), ("precision", 1)):
         gpu_ctx.set_option(name, v)
     gpu_ctx.set_option("rays_per_lane", int(os.environ.get("C5_RAYS_PER_LANE", "1")))
     if os.environ.get("C5_STEEP_RATIO"):  # margin probe: how far can the fp64 fall-back threshold go
