@@ -710,7 +710,11 @@ __global__ __launch_bounds__(256, DMA ? C5_DMA_WAVES : C5_WALK_WAVES) void walk_
         // (kept in a scalar register by hand: as a plain min() the compiler compared it on the vector unit)
         const int n_staged = __builtin_amdgcn_readfirstlane(n_runs < kStageSlots ? n_runs : kStageSlots);
 #if C5_WALK_STAMPS
-        {   // coherence statistics: runs of equal ids against distinct ids among the walking lanes
+        stat_iters += 1u;
+        stat_lanes += static_cast<unsigned>(__popcll(needs));
+#endif
+#if C5_WALK_STAMPS > 1
+        {   // coherence statistics (expensive: -DC5_WALK_STAMPS=2): runs of equal ids against distinct ids among the walking lanes
             unsigned long long seen = 0ull;  // lanes whose id already occurred in a lower lane
             for (int l = 0; l < 64; ++l) {
                 const int v = __builtin_amdgcn_readlane(nb, l);
@@ -719,8 +723,6 @@ __global__ __launch_bounds__(256, DMA ? C5_DMA_WAVES : C5_WALK_WAVES) void walk_
             }
             stat_runs += static_cast<unsigned>(n_runs);
             stat_distinct += static_cast<unsigned>(__popcll(needs & ~seen));
-            stat_iters += 1u;
-            stat_lanes += static_cast<unsigned>(__popcll(needs));
         }
 #endif
         // lane s learns the cell id of slot s: every lane of a group pushes the same id to lane `slot`

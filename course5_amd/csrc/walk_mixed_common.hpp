@@ -13,7 +13,10 @@ namespace c5 {
 
 constexpr uint32_t kExactBit = 1u << 29;  // GeoRecord::w[0]: evaluate this cell from its fp64 CellRecord
 
-constexpr int kMixSlots = 16;        // distinct cells staged per wavefront and step: ONE load instruction
+#ifndef C5_MIX_SLOTS
+#define C5_MIX_SLOTS 16  // (32 measured slower on the C3 frame, equal at 1200 x 900)
+#endif
+constexpr int kMixSlots = C5_MIX_SLOTS;  // distinct cells staged per wavefront and step (a power of two)
 constexpr int kMixStride = 5;        // 16-byte units per slot: 4 of GeoRecord + 1 of OptRecord.  80 bytes = 20
                                      // banks: sixteen slots start on sixteen different 16-byte bank columns
 constexpr unsigned kMixBuckets = 256;

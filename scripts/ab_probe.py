@@ -11,8 +11,8 @@ rest = [a for a in sys.argv[1:] if not a.endswith(".so")]
 precision = int(rest[0]) if len(rest) > 0 else 0
 rounds = int(rest[1]) if len(rest) > 1 else 5
 workload = rest[2] if len(rest) > 2 else "c3"
-res = {"c3": (2400, 1800), "c2": (1200, 900)}[workload]
-xyz, cells, alpha, q = mg.workload(workload)
+res = {"c3": (2400, 1800), "c2": (1200, 900), "c3@1200": (1200, 900), "c3@4800": (4800, 3600)}[workload]
+xyz, cells, alpha, q = mg.workload(workload.split("@")[0])
 out = torch.zeros((res[1], res[0], 2), dtype=torch.float32, device="cuda:0")
 ctxs = []
 for p in paths:
