@@ -27,7 +27,6 @@ LIB_SOURCES = [
     ("exact_kernels.hip", ["-ffp-contract=off"]),   # must round like the reference's host build
     ("walk_kernels.hip", []),
     ("walk_mixed.hip", []),
-    ("walk_mixed2.hip", []),
     ("c_api.hip", []),
     ("adjacency.cpp", ["-x", "c++", "-fopenmp"]),
 ]

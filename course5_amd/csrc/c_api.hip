@@ -132,7 +132,6 @@ struct c5_context {
     int band_rows = 0;
     int order = 0;
     double steep_ratio = 128.0;  // "precision" 1: cells whose fp32 plane terms exceed this many cell extents are evaluated in fp64
-    int rays_per_lane = 1;  // "precision" 1 only: 2 = walk_composite_mixed2 (8 x 16 pixel tile per wavefront)
     int precision = 0;  // 0: fp64 walk, bit-faithful (default); 1: fp32 geometry + fp64 accumulators (walk_mixed.hip)
     int lds_stage = 2;
     int stage_timing = 1;
@@ -516,9 +515,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
         ev_slot = ctx->walk_used++;
         C5_HIP(ctx, hipEventRecord(ctx->walk_a[ev_slot], main_s));
     }
-    if (mixed && ctx->rays_per_lane == 2 && c5::mixed2_fits(ctx->n_cells))
-        c5::launch_walk_mixed2(main_s, wp);
-    else if (mixed)
+    if (mixed)
         c5::launch_walk_mixed(main_s, wp, ctx->tile_shape);
     else
         c5::launch_walk(main_s, wp, ctx->tile_shape);
@@ -1081,9 +1078,6 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
         ctx->lds_stage = static_cast<int>(value) < 0 ? 0 : (static_cast<int>(value) > 2 ? 2 : static_cast<int>(value));
     } else if (n == "integration") {
         ctx->order = static_cast<int>(value) != 0;
-    } else if (n == "rays_per_lane") {
-        if (value != 1 && value != 2) return fail(ctx, C5_ERR_INVALID, "rays_per_lane must be 1 or 2");
-        ctx->rays_per_lane = static_cast<int>(value);
     } else if (n == "steep_ratio") {
         if (!(value >= 0.0)) return fail(ctx, C5_ERR_INVALID, "steep_ratio must be >= 0 (0: never fall back to fp64)");
         ctx->steep_ratio = value;

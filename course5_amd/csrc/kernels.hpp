@@ -96,8 +96,5 @@ void launch_build_records_mixed(hipStream_t s, const GridView& g, const ImagePar
                                 const double* Ytab, double alpha_limit, int order, double steep_ratio);
 void launch_walk_mixed(hipStream_t s, const WalkParams& p, int tile_shape);
 bool mixed_precision_fits(int64_t n_cells, const ImageParams& im);
-// walk_mixed2.hip: the same with two rays per lane (8 x 16 pixel tile per wavefront)
-void launch_walk_mixed2(hipStream_t s, const WalkParams& p);
-bool mixed2_fits(int64_t n_cells);
 
 }  // namespace c5

@@ -81,11 +81,12 @@ __global__ __launch_bounds__(256) void build_records_mixed(GridView g, ImagePara
     // beyond steep_ratio (option "steep_ratio") the cell is marked and the walk evaluates it from its fp64 record instead.
     const double z_lo = fmin(fmin(v[0][2], v[1][2]), fmin(v[2][2], v[3][2]));
     const double z_hi = fmax(fmax(v[0][2], v[1][2]), fmax(v[2][2], v[3][2]));
-    double worst = 0.0;
+    uint32_t steep_slots = 0;  // bit k: face slot k is evaluated in fp64 by the walk
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (!(fabs(c0[k]) <= DBL_MAX)) continue;  // edge-on / flat slot: +-inf, exact
         const double cabs = fabs(c0[k] - static_cast<double>(z0f));
+        double worst = 0.0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             // only the face's own vertices bound its footprint: the fourth vertex is where the plane is
@@ -95,10 +96,21 @@ __global__ __launch_bounds__(256) void build_records_mixed(GridView g, ImagePara
             if (fabs(at_v - v[j][2]) > 1e-6 * (z_hi - z_lo)) continue;
             worst = fmax(worst, cabs + fabs(r.plane[k][1] * (v[j][0] - Xc)) + fabs(r.plane[k][2] * (v[j][1] - Yr)));
         }
+        if (steep_ratio > 0.0 && !(worst <= steep_ratio * (z_hi - z_lo))) steep_slots |= 1u << k;  // (NaN -> steep)
     }
-    const bool steep = steep_ratio > 0.0 && !(worst <= steep_ratio * (z_hi - z_lo));  // (NaN -> steep)
+    const bool steep = steep_slots != 0u;
     if (steep) {
-        const U4* rs = reinterpret_cast<const U4*>(&r);
+        // the same four planes in double precision, about the same origin and depth origin as the fp32 ones:
+        // SteepPlanes in the cell's (otherwise unused) CellRecord slot
+        SteepPlanes sp;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sp.p[k][0] = c0[k] - static_cast<double>(z0f);
+            sp.p[k][1] = r.plane[k][1] * im.step_x;
+            sp.p[k][2] = r.plane[k][2] * im.step_y;
+        }
+        sp.pad[0] = sp.pad[1] = sp.pad[2] = sp.pad[3] = 0.0;
+        const U4* rs = reinterpret_cast<const U4*>(&sp);
         U4* rd = reinterpret_cast<U4*>(g.rec + cell);
 #pragma unroll
         for (int k = 0; k < 8; ++k) rd[k] = rs[k];
@@ -106,7 +118,7 @@ __global__ __launch_bounds__(256) void build_records_mixed(GridView g, ImagePara
     const uint32_t n_up = r.nbr[0] >> kUpperCountShift;
     const int first = (order == 0) ? 0 : 1;  // exit candidates: slots 0..2 walking up, 1..3 walking down
     out.w[0] = (r.nbr[first] & kIdMask) | (n_up << kUpperCountShift) | (steep ? kExactBit : 0u);
-    out.w[1] = r.nbr[first + 1] & kIdMask;
+    out.w[1] = (r.nbr[first + 1] & kIdMask) | (steep_slots << kSteepSlotShift);
     out.w[2] = r.nbr[first + 2] & kIdMask;
     out.w[3] = static_cast<uint32_t>(col0) | (static_cast<uint32_t>(row0) << 16);
 
@@ -348,18 +360,55 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) void w
             // planes (c, gx, gy): g0.xyz | g0.w g1.xy | g1.zw g2.x | g2.yzw
             const float dcol = static_cast<float>(col - static_cast<int>(gw.w & 0xFFFFu));
             const float drow = static_cast<float>(grow - static_cast<int>(gw.w >> 16));
-            const float z0 = fmaf(g0.y, dcol, fmaf(g0.z, drow, g0.x));
-            const float z1 = fmaf(g1.x, dcol, fmaf(g1.y, drow, g0.w));
-            const float z2 = fmaf(g1.w, dcol, fmaf(g2.x, drow, g1.z));
-            const float z3 = fmaf(g2.z, dcol, fmaf(g2.w, drow, g2.y));
+            const float z0f_ = fmaf(g0.y, dcol, fmaf(g0.z, drow, g0.x));
+            const float z1f_ = fmaf(g1.x, dcol, fmaf(g1.y, drow, g0.w));
+            const float z2f_ = fmaf(g1.w, dcol, fmaf(g2.x, drow, g1.z));
+            const float z3f_ = fmaf(g2.z, dcol, fmaf(g2.w, drow, g2.y));
+            // Faces steep against the rays (build_records_mixed; ~2 % of the cells have one): fp32 loses such a face's
+            // depth in the cancellation of its large terms, so the face is evaluated from double-precision
+            // coefficients — about the same lattice origin and depth origin, so the result simply replaces the fp32
+            // depth of that slot and everything below runs as for any other cell.  Per distinct such cell of the
+            // wavefront (usually one) and steep slot, the three coefficients arrive by ONE scalar load (eight SGPRs,
+            // no vector registers) and the lanes inside that cell do two fp64 FMAs.
+            float z0 = z0f_, z1 = z1f_, z2 = z2f_, z3 = z3f_;
+            {
+                const uint32_t steep_bit = gw.x & kExactBit;
+                unsigned long long todo = __builtin_amdgcn_uicmp(steep_bit, 0u, 33 /* ne */);
+                if (todo != 0ull) {
+                    const double dcol_d = static_cast<double>(dcol), drow_d = static_cast<double>(drow);
+                    while (todo != 0ull) {
+                        const int first_lane = __builtin_ctzll(todo);
+                        const int id = __builtin_amdgcn_readlane(nb, first_lane);
+                        const uint32_t slots = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(gw.y), first_lane)) >> kSteepSlotShift;
+                        const bool mine = steep_bit != 0u && nb == id;
+                        todo &= ~__builtin_amdgcn_ballot_w64(mine);
+                        const char* planes = reinterpret_cast<const char*>(P.rec + id);  // uniform address: SteepPlanes
+                        auto dbl = [](int lo, int hi) { return __hiloint2double(hi, lo); };
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if ((slots >> k) & 1u) {  // wave-uniform
+                                SRec8 h;
+                                asm volatile("s_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(h) : "s"(planes), "n"(24 * k) : "memory");
+                                const float zk = static_cast<float>(fma(dbl(h[2], h[3]), dcol_d, fma(dbl(h[4], h[5]), drow_d, dbl(h[0], h[1]))));
+                                if (mine) {
+                                    if (k == 0) z0 = zk;
+                                    if (k == 1) z1 = zk;
+                                    if (k == 2) z2 = zk;
+                                    if (k == 3) z3 = zk;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
             const uint32_t n_up = gw.x >> kUpperCountShift;  // 1..3: slot 0 always upper, slot 3 always lower
             const bool up1 = n_up > 1u, up2 = n_up > 2u;
             const float u1 = up1 ? z1 : INFINITY, l1 = up1 ? -INFINITY : z1;
             const float u2 = up2 ? z2 : INFINITY, l2 = up2 ? -INFINITY : z2;
             const float z_top = min3_f32(z0, u1, u2);
             const float z_bot = max3_f32(z3, l1, l2);
-            float dz = z_top - z_bot;  // chord through the cell (line.cpp:124-131)
-            uint32_t w_out;            // neighbour word of the exit face
+            const float dz = z_top - z_bot;  // chord through the cell (line.cpp:124-131)
+            uint32_t w_out;                  // neighbour word of the exit face
             float z_exit;
             if (kUp) {  // leaves through the lowest upper face: ids of slots 0, 1, 2
                 w_out = (z0 == z_top) ? gw.x : (u1 == z_top) ? gw.y : gw.z;
@@ -368,73 +417,8 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) void w
                 w_out = (z3 == z_bot) ? gw.z : (l2 == z_bot) ? gw.y : gw.x;
                 z_exit = z_bot;
             }
-            bool has_exit = fabsf(z_exit) < INFINITY;
-            double dz_tau = static_cast<double>(dz);
-
-            // Cells with a face steep against the rays (build_records_mixed: kExactBit; ~2 % of cells): fp32 would
-            // lose the chord in the cancellation, so they are evaluated from their fp64 record.  Per distinct such
-            // cell of the wavefront (usually one) the record is fetched with SCALAR loads — 128 bytes into SGPRs,
-            // no vector registers, so the kernel keeps its 8 wavefronts per SIMD — and the lanes inside that cell
-            // redo the four planes in fp64 with the coefficients as scalar operands.
-            const bool steep = (gw.x & kExactBit) != 0u;
-            unsigned long long todo = __builtin_amdgcn_ballot_w64(steep);
-            while (todo != 0ull) {
-                const int first_lane = __builtin_ctzll(todo);
-                const int id = __builtin_amdgcn_readlane(nb, first_lane);
-                const bool mine = steep && nb == id;
-                todo &= ~__builtin_amdgcn_ballot_w64(mine);
-                const CellRecord* rec = P.rec + id;  // uniform address
-                // two rounds of 64 bytes through the same sixteen scalar registers (the kernel's SGPR count, like its
-                // VGPR count, decides how many wavefronts a SIMD holds)
-                auto dbl = [](int a, int b) { return __hiloint2double(b, a); };
-                double dx = 0.0, dy = 0.0, e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;
-                uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-                if (mine) {
-                    dx = P.Xtab[col];
-                    dy = P.Ytab[grow];
-                }
-                {   // CellRecord bytes 0-63: x0 y0 | plane[0] c gx gy | plane[1] c gx gy
-                    SRec16 h;
-                    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(h) : "s"(rec) : "memory");
-                    if (mine) {
-                        dx -= dbl(h[0], h[1]);
-                        dy -= dbl(h[2], h[3]);
-                        e0 = fma(dbl(h[6], h[7]), dx, fma(dbl(h[8], h[9]), dy, dbl(h[4], h[5])));
-                        e1 = fma(dbl(h[12], h[13]), dx, fma(dbl(h[14], h[15]), dy, dbl(h[10], h[11])));
-                    }
-                }
-                {   // bytes 64-127: plane[2] | plane[3] | nbr[4]
-                    SRec16 h;
-                    asm volatile("s_load_dwordx16 %0, %1, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(h) : "s"(rec) : "memory");
-                    if (mine) {
-                        e2 = fma(dbl(h[2], h[3]), dx, fma(dbl(h[4], h[5]), dy, dbl(h[0], h[1])));
-                        e3 = fma(dbl(h[8], h[9]), dx, fma(dbl(h[10], h[11]), dy, dbl(h[6], h[7])));
-                    }
-                    q0 = static_cast<uint32_t>(h[12]);
-                    q1 = static_cast<uint32_t>(h[13]);
-                    q2 = static_cast<uint32_t>(h[14]);
-                    q3 = static_cast<uint32_t>(h[15]);
-                }
-                if (mine) {
-                    const uint32_t nu = q0 >> kUpperCountShift;  // wave-uniform
-                    const double a1 = nu > 1u ? e1 : INFINITY, b1 = nu > 1u ? -INFINITY : e1;
-                    const double a2 = nu > 2u ? e2 : INFINITY, b2 = nu > 2u ? -INFINITY : e2;
-                    const double zt = fmin(e0, fmin(a1, a2)), zb = fmax(e3, fmax(b1, b2));
-                    dz_tau = zt - zb;
-                    dz = static_cast<float>(dz_tau);
-                    double ze;
-                    if (kUp) {
-                        w_out = (e0 == zt) ? q0 : (a1 == zt) ? q1 : q2;
-                        ze = zt;
-                    } else {
-                        w_out = (e3 == zb) ? q3 : (b2 == zb) ? q2 : q1;
-                        ze = zb;
-                    }
-                    // leaving the grid from here: the exit depth goes to the lane's s_cur now (it is absolute already)
-                    if ((w_out & kIdMask) == kNoCell && fabs(ze) < INFINITY) my_scur[lane] = fmin(my_scur[lane], kUp ? -ze : ze);
-                    has_exit = false;
-                }
-            }
+            const bool has_exit = fabsf(z_exit) < INFINITY;
+            const double dz_tau = static_cast<double>(dz);
             if (dz > 0.0f && dz < INFINITY) {
                 ++n_seg;
                 tau = fma(dz_tau, static_cast<double>(pend_opt.x), tau);  // line.cpp:189 (unclamped alpha)

@@ -1,4 +1,4 @@
-// Helpers shared by the mixed-precision walk kernels (walk_mixed.hip: one ray per lane; walk_mixed2.hip: two).
+// Helpers of the mixed-precision walk kernel (walk_mixed.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -11,7 +11,16 @@
 
 namespace c5 {
 
-constexpr uint32_t kExactBit = 1u << 29;  // GeoRecord::w[0]: evaluate this cell from its fp64 CellRecord
+constexpr uint32_t kExactBit = 1u << 29;  // GeoRecord::w[0]: the cell has a face evaluated in fp64 (SteepPlanes)
+constexpr int kSteepSlotShift = 28;       // GeoRecord::w[1] bits 28-31: which face slots those are
+// What a steep cell keeps in its CellRecord slot (128 bytes): the four face planes (c, gx, gy) in double precision
+// about the GeoRecord's lattice origin and depth origin.
+struct alignas(16) SteepPlanes {
+    double p[4][3];
+    double pad[4];
+};
+static_assert(sizeof(SteepPlanes) == sizeof(CellRecord), "SteepPlanes lives in the cell's CellRecord slot");
+using SRec8 = int __attribute__((ext_vector_type(8)));
 
 #ifndef C5_MIX_SLOTS
 #define C5_MIX_SLOTS 16  // (32 measured slower on the C3 frame, equal at 1200 x 900)

@@ -157,7 +157,6 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  sliver more or less than the reference.
  *   "steep_ratio"  "precision" 1: a cell whose fp32 plane terms exceed this many times its extent along the rays is
  *                  evaluated from its fp64 record instead (default 128; 0: never).
- *   "rays_per_lane" "precision" 1: 2 = two rays per lane on an 8x16 tile per wavefront (measured slower; default 1).
  *   "algorithm"    0 (default for conforming grids): face-adjacency walk.  1: bin_sort_resolve, the
  *                  reference's own algorithm on the GPU (every face of every cell scan-converted onto
  *                  the pixels, per-pixel sort by z, integrate) — handles tet soups, overlapping and

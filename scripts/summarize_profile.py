@@ -54,14 +54,16 @@ def write_roofline(tag, walk, c):
     if cycles:
         if get("SQ_ACTIVE_INST_VALU"):  # quad-cycles a SIMD's vector pipe was executing, summed over SIMDs
             units["valu"] = {"frac": 4.0 * get("SQ_ACTIVE_INST_VALU") / (cycles * n_simd),
-                             "what": "4 x SQ_ACTIVE_INST_VALU / (cycles x 1024 SIMDs): share of the launch the vector pipes were executing"}
+                             "what": "4 x SQ_ACTIVE_INST_VALU / (cycles x 1024 SIMDs): share of the launch the vector pipes were executing, "
+                                     "counting every vector instruction as 4 cycles - an UPPER bound: 32-bit instructions issue in about "
+                                     "2 cycles on gfx950, 64-bit and packed ones in about 4 (scripts/probes/valu_rate_probe.hip)"}
         if get("SQ_LDS_IDX_ACTIVE"):
             units["lds"] = {"frac": get("SQ_LDS_IDX_ACTIVE") / (cycles * n_cu),
                             "what": "SQ_LDS_IDX_ACTIVE / (cycles x 256 CUs): share of the launch the LDS arrays were busy",
                             "bank_conflict_share": (get("SQ_LDS_BANK_CONFLICT") or 0.0) / get("SQ_LDS_IDX_ACTIVE")}
         if get("SQ_WAVE_CYCLES"):
             units["wave_slots"] = {"frac": 4.0 * get("SQ_WAVE_CYCLES") / (cycles * n_simd * 8),
-                                   "what": "4 x SQ_WAVE_CYCLES / (cycles x 8192 wavefront slots): average occupancy (the fp64 walk's 80 VGPRs allow 6 of 8 per SIMD, the mixed walk's 64 all 8)"}
+                                   "what": "4 x SQ_WAVE_CYCLES / (cycles x 8192 wavefront slots): average occupancy (the fp64 walk's 72 VGPRs allow 7 of 8 per SIMD, the mixed walk's 58 all 8)"}
         if get("SQ_WAIT_ANY") and get("SQ_WAVE_CYCLES"):
             units["waiting"] = {"frac": get("SQ_WAIT_ANY") / get("SQ_WAVE_CYCLES"),
                                 "what": "SQ_WAIT_ANY / SQ_WAVE_CYCLES: share of a wavefront's life parked on s_waitcnt"}
@@ -87,8 +89,9 @@ def write_roofline(tag, walk, c):
                   key=lambda kv: kv[1], default=None)
     if busiest:
         out["limiter"] = {"name": busiest[0], "frac": busiest[1],
-                          "note": "the busiest unit; no unit is saturated - a step is a dependent chain (election -> load -> "
-                                  "LDS -> geometry -> exit) and the resident wavefronts do not cover all of it"}
+                          "note": "the busiest unit by its counter; no unit is saturated - a step is a dependent chain (election -> "
+                                  "load -> LDS -> geometry -> exit) and the resident wavefronts do not cover all of it; removing "
+                                  "vector instructions did not shorten the launch (DESIGN.md section 4.1)"}
     with open(os.path.join(PROF, f"roofline{SUFFIX}.json"), "w") as f:
         json.dump(out, f, indent=1)
     lines = [f"walk_composite per launch: {cycles:.4g} shader cycles" if cycles else ""]

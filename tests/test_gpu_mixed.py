@@ -20,13 +20,11 @@ def _mixed(gpu_ctx):
         gpu_ctx.set_solid(k, np.zeros((0, 12)))
     for name, v in (("tile", 2), ("integration", 0), ("lds_stage", 2), ("algorithm", 0), ("xcd_mode", 2), ("precision", 1)):
         gpu_ctx.set_option(name, v)
-    gpu_ctx.set_option("rays_per_lane", int(os.environ.get("C5_RAYS_PER_LANE", "1")))
     if os.environ.get("C5_STEEP_RATIO"):  # margin probe: how far can the fp64 fall-back threshold go
         gpu_ctx.set_option("steep_ratio", float(os.environ["C5_STEEP_RATIO"]))
     gpu_ctx.set_row_range(0, -1)
     gpu_ctx.set_row_tiles(0, 0, 1)
     yield
-    gpu_ctx.set_option("rays_per_lane", 1)
     gpu_ctx.set_option("precision", 0)
     gpu_ctx.set_option("integration", 0)
     gpu_ctx.set_option("tile", 2)
@@ -158,30 +156,3 @@ def test_c3_full_frame_mixed_against_the_cpu_oracle(gpu_ctx, oracle_port):
     gpu_ctx.set_option("integration", 1)
     ftb, _ = _render(gpu_ctx, rots, 2400, 1800)
     assert compare(ftb, exact)["outliers"] == 0
-
-
-def test_two_rays_per_lane_variant_is_the_same_walk(gpu_ctx, oracle_port):
-    """Option "rays_per_lane" 2 (walk_mixed2.hip): an 8 x 16 pixel tile per wavefront, two rays per lane sharing
-    the election and the staging loads.  Same records, same arithmetic per ray: the image is bit-equal to the
-    one-ray mixed kernel's, on the non-convex ball (re-entries, steep cells, more than sixteen distinct cells per
-    step) and sharded; measured slower, kept as the record of the experiment."""
-    xyz, cells, alpha, q = mg.workload("c2")
-    gpu_ctx.upload_grid(xyz, cells, alpha, q)
-    for view, res, order in (((0.1, 0.07), (400, 300), 0), ((1.3, -0.4), (333, 217), 1)):
-        gpu_ctx.set_option("integration", order)
-        rots = mg.view_rotations(*view)
-        gpu_ctx.set_option("rays_per_lane", 1)
-        one, st1 = _render(gpu_ctx, rots, *res)
-        gpu_ctx.set_option("rays_per_lane", 2)
-        two, st2 = _render(gpu_ctx, rots, *res)
-        assert np.array_equal(one.view(np.uint32), two.view(np.uint32))
-        for k in ("segments", "covered_pixels", "entries", "steps"):
-            assert st1[k] == st2[k], k
-        strips = []
-        for rank in range(3):
-            gpu_ctx.set_row_tiles(16, rank, 3)
-            strips.append(gpu_ctx.render())
-        gpu_ctx.set_row_tiles(0, 0, 1)
-        assert np.array_equal(sharding.assemble(strips, res[1], 16, 3).view(np.uint32), one.view(np.uint32))
-    ref = oracle_port.render(xyz, cells, alpha, q, mg.view_rotations(1.3, -0.4), 333, 217, mg.REFERENCE_BOUNDS, threads=8)
-    assert_images_match(two, ref["image"], "two rays per lane vs oracle")
