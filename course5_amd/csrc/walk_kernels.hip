@@ -628,7 +628,9 @@ __global__ __launch_bounds__(256, DMA ? C5_DMA_WAVES : C5_WALK_WAVES) void walk_
         const uint32_t ids_at = (uint32_t)(uintptr_t)(LdsInts)(my_elect + kBuckets1 + 64);  // LDS byte address
         const int s_ = lane / kSlotStride, pc = lane - s_ * kSlotStride;
         const bool has = s_ < kDmaSlots && pc < 10;
-        dma_id_at = has ? ids_at + 4u * static_cast<uint32_t>(s_) : 0xFFFFF000u;
+        // (idle lanes: a slot no pass ever stages — still an address inside the workgroup's LDS, so that the id reads
+        // below need no predicate and are all in flight before the first load is issued)
+        dma_id_at = ids_at + 4u * static_cast<uint32_t>(has ? s_ : 60);
         dma_pitch = pc < 8 ? 7u : 5u;
         dma_off = pc < 8 ? 16u * static_cast<uint32_t>(pc) : opt_delta + 16u * static_cast<uint32_t>(pc - 8);
     }
@@ -744,12 +746,14 @@ __global__ __launch_bounds__(256, DMA ? C5_DMA_WAVES : C5_WALK_WAVES) void walk_
 #pragma clang diagnostic pop
         if (DMA) {
             const uint32_t ids_end = (uint32_t)(uintptr_t)(LdsInts)(my_elect + kBuckets1 + 64) + 4u * static_cast<uint32_t>(n_staged);
+            uint32_t id_of_pass[kDmaPasses];
+#pragma unroll
+            for (int j = 0; j < kDmaPasses; ++j) id_of_pass[j] = static_cast<uint32_t>(((LdsInts)(uintptr_t)dma_id_at)[kDmaSlots * j]);
 #pragma unroll
             for (int j = 0; j < kDmaPasses; ++j) {
                 if (j == 0 || kDmaSlots * j < n_staged) {  // wave-uniform: does the pass reach a staged slot at all
                     if (dma_id_at < ids_end - 4u * kDmaSlots * j) {  // this lane's slot 5 j + s is staged (idle lanes: never)
-                        const uint32_t id_ = static_cast<uint32_t>(((LdsInts)(uintptr_t)dma_id_at)[kDmaSlots * j]);
-                        const uint32_t off = (id_ << dma_pitch) + dma_off;
+                        const uint32_t off = (id_of_pass[j] << dma_pitch) + dma_off;
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rec_bytes + off),
                                                          (__attribute__((address_space(3))) void*)(my_stage + kDmaSlots * kSlotStride * j), 16, 0, 0);
                     }

@@ -9,8 +9,8 @@ name, va, vb = sys.argv[1], float(sys.argv[2]), float(sys.argv[3])
 rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 workload = sys.argv[5] if len(sys.argv) > 5 else "c3"
 precision = int(sys.argv[6]) if len(sys.argv) > 6 else 0
-res = {"c3": (2400, 1800), "c2": (1200, 900)}[workload]
-xyz, cells, alpha, q = mg.workload(workload)
+res = {"c3": (2400, 1800), "c2": (1200, 900), "c3@1200": (1200, 900), "c3@4800": (4800, 3600)}[workload]
+xyz, cells, alpha, q = mg.workload(workload.split("@")[0])
 outs, ctxs = [], []
 for v in (va, vb):
     ctx = capi.Context(0)
