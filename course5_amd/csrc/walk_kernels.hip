@@ -397,10 +397,15 @@ constexpr int kStageSlots = C5_STAGE_SLOTS;
 #define C5_ELECT_BUCKETS 256
 #endif
 constexpr unsigned kBuckets1 = C5_ELECT_BUCKETS;  // first leader table (power of two)   // runs of equal cell ids staged per wavefront and step (more: direct loads)
-// One staged cell in LDS, 16-byte units: 8 of CellRecord, 2 of CellOptics, 1 pad.  176 bytes = 44 banks:
-// sixteen consecutive slots start on sixteen different 16-byte bank columns, so a ds_read_b128 whose
-// 16-lane groups span up to 16 different slots is conflict-free (MI355X_MICROARCH.md, LDS table).
-constexpr int kSlotStride = 11;
+// One staged cell in LDS, 16-byte units: 8 of CellRecord, 2 of CellOptics, no pad.  160 bytes = 40 banks: eight
+// consecutive slots start on eight different 16-byte bank columns (slots s and s + 8 share theirs).  With a pad
+// unit (176 bytes: sixteen different columns, no conflict at all) a DMA pass stages five slots instead of six:
+// measured, the sixth slot is worth more than the missing conflicts cost (C3 frame 0.557 -> 0.549 ms, 1200 x 900
+// 0.326 -> 0.318).
+#ifndef C5_SLOT_STRIDE
+#define C5_SLOT_STRIDE 10
+#endif
+constexpr int kSlotStride = C5_SLOT_STRIDE;
 using V2 = double __attribute__((ext_vector_type(2)));  // 16 bytes as one SSA value (never an alloca)
 __device__ __forceinline__ D2 as_d2(V2 v) { return D2{v.x, v.y}; }
 
@@ -614,12 +619,10 @@ __global__ __launch_bounds__(256, DMA ? C5_DMA_WAVES : C5_WALK_WAVES) void walk_
     const int sub4 = sub << 2, so4 = so << 2;  // ds_bpermute byte addresses of slot `sub` / `so`
     V2* const put_rec = my_stage + sub * kSlotStride + piece;         // + 8 * pass * kSlotStride
     V2* const put_opt = my_stage + so * kSlotStride + 8 + (lane & 1);
-    // DMA: per pass, the LDS address of this lane's slot id (beyond every limit where the lane has nothing to
-    // fetch), log2 of the bytes per cell of the array its piece comes from and the piece's offset from P.rec
-    // DMA: a pass stages kDmaSlots = 5 whole slots (55 lanes; the last nine idle), so that a lane fetches the same
+    // DMA: a pass stages kDmaSlots = 6 whole slots (60 lanes; the last four idle), so that a lane fetches the same
     // piece of the same slot-within-the-pass in every pass: three registers hold where that slot's cell id is
-    // posted (beyond every limit where the lane has nothing to fetch), log2 of the bytes per cell of the array the
-    // piece comes from and the piece's offset from P.rec.  Pass j: slots 5 j ... 5 j + 4, LDS units from 55 j.
+    // posted, log2 of the bytes per cell of the array the piece comes from and the piece's offset from P.rec.
+    // Pass j: slots 6 j ... 6 j + 5, LDS units from 60 j.
     constexpr int kDmaSlots = 64 / kSlotStride;
     constexpr int kDmaPasses = (kStageSlots + kDmaSlots - 1) / kDmaSlots;
     uint32_t dma_id_at = 0, dma_pitch = 0, dma_off = 0;
@@ -752,7 +755,7 @@ __global__ __launch_bounds__(256, DMA ? C5_DMA_WAVES : C5_WALK_WAVES) void walk_
 #pragma unroll
             for (int j = 0; j < kDmaPasses; ++j) {
                 if (j == 0 || kDmaSlots * j < n_staged) {  // wave-uniform: does the pass reach a staged slot at all
-                    if (dma_id_at < ids_end - 4u * kDmaSlots * j) {  // this lane's slot 5 j + s is staged (idle lanes: never)
+                    if (dma_id_at < ids_end - 4u * kDmaSlots * j) {  // this lane's slot kDmaSlots j + s is staged (idle lanes: never)
                         const uint32_t off = (id_of_pass[j] << dma_pitch) + dma_off;
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rec_bytes + off),
                                                          (__attribute__((address_space(3))) void*)(my_stage + kDmaSlots * kSlotStride * j), 16, 0, 0);
