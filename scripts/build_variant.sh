@@ -10,5 +10,5 @@ cd course5_amd
 mkdir -p _build/var_$name
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wextra -Wno-unused-parameter -I ../include "$@" -c csrc/walk_kernels.hip -o _build/var_$name/walk_kernels.o
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wextra -Wno-unused-parameter -I ../include "$@" -c csrc/walk_mixed.hip -o _build/var_$name/walk_mixed.o
-hipcc -shared -fPIC --offload-arch=gfx950 -o libcourse5_hip_$name.so _build/exact_kernels.o _build/var_$name/walk_kernels.o _build/var_$name/walk_mixed.o _build/walk_mixed2.o _build/c_api.o _build/adjacency.o -fopenmp
+hipcc -shared -fPIC --offload-arch=gfx950 -o libcourse5_hip_$name.so _build/exact_kernels.o _build/var_$name/walk_kernels.o _build/var_$name/walk_mixed.o _build/c_api.o _build/adjacency.o -fopenmp
 ls -la libcourse5_hip_$name.so
