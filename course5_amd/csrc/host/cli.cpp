@@ -47,6 +47,7 @@ const option_spec kOptions[] = {
     {"png_range", 0, true, "lo,hi: fixed colour range for every frame (default: each frame's own finite range)", nullptr},
     {"raw_vti", 0, false, "write the .vti uncompressed (default: zlib blocks, like vtkXMLImageDataWriter)", nullptr},
     {"reference_algorithm", 0, false, "bin + sort + resolve on the GPU (for grids with overlapping cells)", nullptr},
+    {"rccl_selftest", 0, false, "load librccl, open a communicator on --device and run the tile exchange's calls against itself", nullptr},
     {"selftest_vti", 0, true, "write a synthetic 48x32 image to this .vti and exit (checks the writer, no GPU)", nullptr},
     {"parse_only", 0, false, "read the input and generate the solids, print sizes, no GPU work", nullptr},
     {"dump_solids", 0, true, "write generated solid tets to this file (int64 count + doubles per object)", nullptr},
@@ -149,6 +150,7 @@ bool program_options(int argc, char** argv, std::ostream& out) {
         }
         else if (n == "reference_algorithm") cfg.reference_algorithm = true;
         else if (n == "selftest_vti") cfg.selftest_vti = v;
+        else if (n == "rccl_selftest") cfg.rccl_selftest = true;
         else if (n == "parse_only") cfg.parse_only = true;
         else if (n == "dump_solids") cfg.dump_solids = v;
         else if (n == "frames") cfg.frames = static_cast<std::size_t>(std::max(1ll, to_integer(n, v)));
@@ -194,7 +196,7 @@ bool program_options(int argc, char** argv, std::ostream& out) {
         print_usage(out);
         return false;
     }
-    if (!cfg.selftest_vti.empty()) return true;
+    if (!cfg.selftest_vti.empty() || cfg.rccl_selftest) return true;
     if (cfg.bench > 0 && have_file && !have_dest) have_dest = true;  // a benchmark writes no file
     if (cfg.exchange != "host" && cfg.exchange != "rccl" && cfg.exchange != "p2p")
         throw std::runtime_error("the argument ('" + cfg.exchange + "') for option '--exchange' is invalid");

@@ -38,6 +38,7 @@ struct render_config {
     double png_lo = 0, png_hi = 0;
     bool raw_vti = false;         // write uncompressed appended data instead of zlib blocks
     bool reference_algorithm = false;  // force the bin-sort-resolve path (tet soups with overlapping cells)
+    bool rccl_selftest = false;   // load librccl, bring up a communicator on --device and run the exchange's call pattern against itself
     std::string selftest_vti;     // write a small synthetic image with the configured encoding and exit (no GPU)
     std::string dump_solids;      // write the generated solid tets (raw doubles) for inspection
     std::size_t frames = 1;       // > 1: sweep, grid stays resident on the GPU

@@ -50,6 +50,10 @@ int main(int argc, char** argv) try {
     const render_config& config = app::instance().config;
     if (!program_options(argc, argv, std::cout)) return 0;  // main.cpp:74-78
 
+    if (config.rccl_selftest) {
+        std::cout << rccl_selftest(config.device) << std::endl;
+        return 0;
+    }
     if (!config.selftest_vti.empty()) {  // writer check without a GPU: value = x + 100 y (+0.5 on ch1), one NaN pixel
         const int w = 48, h = 32;
         std::vector<float> px(static_cast<size_t>(w) * h * 2);

@@ -153,6 +153,58 @@ struct multi_gpu {
     }
 };
 
+std::string rccl_selftest(int device) {
+    rccl_api& nccl = rccl_api::get();
+    if (!nccl.ok) throw std::runtime_error(nccl.error);
+    hip_check(hipSetDevice(device), "hipSetDevice");
+    ncclComm_t comm = nullptr;
+    int devs[1] = {device};
+    ncclResult_t rc = nccl.CommInitAll(&comm, 1, devs);
+    if (rc != ncclSuccess) throw std::runtime_error(std::string("ncclCommInitAll: ") + nccl.GetErrorString(rc));
+    // a "strip" of 5 tiles (the last one short) scattered to every other tile of a "frame", as rank r's tiles are
+    // scattered into the root's image
+    const std::size_t row_floats = 2 * 301, tile_floats = row_floats * kTileRows;
+    const int n_tiles = 5, last_rows = 7;
+    const std::size_t strip_floats = tile_floats * (n_tiles - 1) + row_floats * last_rows, frame_floats = tile_floats * 2 * n_tiles;
+    std::vector<float> host(strip_floats);
+    for (std::size_t k = 0; k < strip_floats; ++k) host[k] = static_cast<float>(k % 100003) + 0.25f;
+    float *strip = nullptr, *frame = nullptr;
+    hipStream_t s = nullptr;
+    hip_check(hipMalloc(reinterpret_cast<void**>(&strip), strip_floats * sizeof(float)), "hipMalloc");
+    hip_check(hipMalloc(reinterpret_cast<void**>(&frame), frame_floats * sizeof(float)), "hipMalloc");
+    hip_check(hipStreamCreate(&s), "hipStreamCreate");
+    hip_check(hipMemcpy(strip, host.data(), strip_floats * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy");
+    hip_check(hipMemset(frame, 0, frame_floats * sizeof(float)), "hipMemset");
+    rc = nccl.GroupStart();
+    for (int lt = 0; lt < n_tiles && rc == ncclSuccess; ++lt) {
+        const std::size_t count = (lt + 1 == n_tiles ? static_cast<std::size_t>(last_rows) : static_cast<std::size_t>(kTileRows)) * row_floats;
+        rc = nccl.Send(strip + tile_floats * lt, count, ncclFloat, 0, comm, s);
+        if (rc == ncclSuccess) rc = nccl.Recv(frame + tile_floats * (2 * lt + 1), count, ncclFloat, 0, comm, s);
+    }
+    const ncclResult_t end = nccl.GroupEnd();
+    if (rc != ncclSuccess || end != ncclSuccess)
+        throw std::runtime_error(std::string("RCCL self-test: ") + nccl.GetErrorString(rc != ncclSuccess ? rc : end));
+    hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+    std::vector<float> back(frame_floats);
+    hip_check(hipMemcpy(back.data(), frame, frame_floats * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy");
+    std::size_t wrong = 0;
+    for (int gt = 0; gt < 2 * n_tiles; ++gt) {
+        const int lt = gt / 2;
+        const std::size_t rows = (gt % 2 == 0) ? 0 : (lt + 1 == n_tiles ? last_rows : kTileRows);
+        for (std::size_t k = 0; k < tile_floats; ++k) {
+            const float want = k < rows * row_floats ? host[tile_floats * static_cast<std::size_t>(lt) + k] : 0.0f;
+            wrong += back[tile_floats * static_cast<std::size_t>(gt) + k] != want;
+        }
+    }
+    (void)nccl.CommDestroy(comm);
+    (void)hipStreamDestroy(s);
+    (void)hipFree(strip);
+    (void)hipFree(frame);
+    if (wrong) throw std::runtime_error("RCCL self-test: " + std::to_string(wrong) + " floats in the wrong place");
+    return "RCCL self-test ok: librccl loaded, communicator over device " + std::to_string(device) + ", " + std::to_string(n_tiles) +
+           " grouped ncclSend/ncclRecv pairs landed " + std::to_string(strip_floats) + " floats at their tile offsets";
+}
+
 // ------------------------------------------------------------------------------------------------
 // automatic boundaries (plane.cpp:278-288 over object3d_base::get_boundaries, object3d_base.cpp:221-255, over
 // tetra::get_boundaries, tetra.cpp:18-42): the x / y bounding box of every object's TRANSFORMED vertices.  The

@@ -122,5 +122,11 @@ private:
 // boundaries are given (plane.cpp:278-288)
 std::array<double, 4> bounding_box(std::vector<object3d_base>& objects3d);
 
+// What a one-GPU box can check of the RCCL exchange: librccl loads, every entry point the exchange uses resolves,
+// a communicator comes up (ncclCommInitAll over the one device), and the exchange's own call pattern — a group of
+// ncclSend / ncclRecv pairs that land 16-row tiles at their final offsets of a frame — moves the right bytes, the
+// device sending to itself.  Returns a line for the log; throws on any failure.
+std::string rccl_selftest(int device);
+
 // "0", "0-7", "0,2,4", "0,0" (the same GPU twice: rehearsal of the multi-GPU path on one GPU)
 std::vector<int> parse_device_list(const std::string& text);

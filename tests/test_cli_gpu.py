@@ -250,3 +250,13 @@ def test_course_sweep_writes_colour_mapped_frames(tmp_path):
         lower_half = (~nan) & (img[..., 1] < 0.25)
         order = np.argsort(img[..., 1][lower_half], kind="stable")
         assert (np.diff(rgb[..., 0][lower_half][order]) >= 0).all()
+
+
+def test_rccl_entry_points_and_call_pattern_on_one_gpu():
+    """What one GPU can prove of `--exchange rccl` (the 8-GPU exchange itself only runs on a real node): librccl is
+    loaded on demand, every entry point the exchange uses resolves, a communicator comes up, and the exchange's
+    call pattern — one group of ncclSend / ncclRecv pairs landing 16-row tiles (the last one short) at their
+    final offsets — moves exactly the right floats, the device sending to itself."""
+    r = subprocess.run([COURSE, "--rccl_selftest"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+    assert "RCCL self-test ok" in r.stdout and "5 grouped ncclSend/ncclRecv pairs" in r.stdout
