@@ -511,6 +511,26 @@ void launch_transform_aos(hipStream_t s, const double* in, double* out, int64_t 
     hipLaunchKernelGGL(transform_points_aos, dim3(blocks), dim3(256), 0, s, in, out, n, R);
 }
 
+__global__ __launch_bounds__(256) void mask_overlay(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n4) {
+    const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (i >= n4) return;
+    const uint4 v = src[i];
+    if ((v.x | v.y | v.z | v.w) == 0u) return;  // most of the image: nothing to lay over
+    uint4 d = dst[i];
+    d.x = v.x ? v.x : d.x;
+    d.y = v.y ? v.y : d.y;
+    d.z = v.z ? v.z : d.z;
+    d.w = v.w ? v.w : d.w;
+    dst[i] = d;
+}
+
+void launch_mask_overlay(hipStream_t s, const uint32_t* src, uint32_t* dst, int64_t n_padded) {
+    const int64_t n4 = n_padded / 4;  // masks are padded to 1024 entries
+    if (n4 <= 0) return;
+    hipLaunchKernelGGL(mask_overlay, dim3(static_cast<unsigned>((n4 + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n4);
+}
+
 void launch_solid_mask_raster(hipStream_t s, const double* pts, const int4* faces, int64_t n_faces,
                               uint32_t value, const double* Ytab, const ImageParams& im, uint32_t* mask,
                               int lanes_per_face) {

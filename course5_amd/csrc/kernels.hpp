@@ -79,6 +79,8 @@ void launch_resolve(hipStream_t s, const GridView& g, const ImageParams& im, con
                     const uint32_t* mask, const SolidTable& solids, double alpha_limit, float2* out,
                     FrameCounters* counters);
 size_t segment_bytes();
+// dst[p] = src[p] wherever src[p] != 0 (a cached solid mask laid over the frame's mask, in slot order)
+void launch_mask_overlay(hipStream_t s, const uint32_t* src, uint32_t* dst, int64_t n_padded);
 
 // walk_kernels.hip
 void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, int order);

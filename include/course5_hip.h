@@ -173,6 +173,10 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *   "band_rows"    tuning: rows per super-block ("xcd_mode" 2, 0 = default 32) or band (1, default 16).
  *   "fuse_setup"   1: the per-cell records and the boundary entry lists are built by ONE launch of interleaved
  *                  workgroups; 0 (default): two launches.  Same results; measured slower fused.
+ *   "solid_cache"  1 (default): a solid whose view and image are the same as in the frame before (the accretor sphere
+ *                  never rotates, main.cpp:116; in a -D sweep only the lobe moves) is rastered once into a mask of its
+ *                  own, which later frames lay over theirs; 0: every solid is transformed and rastered every frame.
+ *                  Same masks either way.
  *   "overlap_setup" 1: entry lists and solid mask are built on a side stream while build_records
  *                  runs (only when "stage_timing" is 0).  Default 0: measured no faster.
  *   "pipeline"     1: two frame slots; the per-view setup of frame k + 1 runs on a second stream while

@@ -119,3 +119,62 @@ def test_c5_donor_sweep_with_lobe_and_sphere_on_the_1m_grid(gpu_ctx, oracle_port
         gpu_ctx.set_solid(0, np.zeros((0, 12)))
         gpu_ctx.set_solid(1, np.zeros((0, 12)))
     assert all(not np.array_equal(masks[0], m) for m in masks[1:])
+
+
+def test_a_solids_own_mask_follows_every_change(gpu_ctx, product_solids):
+    """Option "solid_cache" (default on): a solid whose view and image are those of the frame before is rastered once
+    into a mask of its own and laid over later frames.  Every way that mask can go stale — the solid's view, the
+    other solid's view, the image, the solid's geometry — is walked through, each state rendered several frames in a
+    row (so that the first, the mask-building and the overlay frame all occur), and every frame must equal the one
+    rendered with the cache switched off, bit for bit."""
+    xyz, cells, alpha, q = mg.workload("g2")
+    gpu_ctx.upload_grid(xyz, cells, alpha, q)
+    rots = mg.view_rotations(0.1, 0.07)
+    gpu_ctx.set_view(rots)
+    lobe, sphere = product_solids
+    lobe_rots = lambda d: np.vstack([[1.0, d * PI, 1.0], rots])  # noqa: E731
+
+    def frames(n):
+        out = []
+        for _ in range(n):
+            out.append(gpu_ctx.render().copy())
+        return out
+
+    def check(label):
+        cached = frames(4)
+        gpu_ctx.set_option("solid_cache", 0)
+        plain = gpu_ctx.render()
+        gpu_ctx.set_option("solid_cache", 1)
+        for k, img in enumerate(cached):
+            assert np.array_equal(img.view(np.uint32), plain.view(np.uint32)), (label, k)
+        return plain
+
+    try:
+        gpu_ctx.set_image(600, 450, mg.REFERENCE_BOUNDS)
+        gpu_ctx.set_solid(0, lobe.reshape(-1, 12), float("nan"))
+        gpu_ctx.set_solid(1, sphere.reshape(-1, 12), 7.5)
+        gpu_ctx.set_solid_view(0, lobe_rots(0.0))
+        gpu_ctx.set_solid_view(1, np.zeros((0, 3)))
+        a = check("both still")
+        assert np.isnan(a[..., 0]).sum() > 1000 and (a[..., 0] == 7.5).sum() > 50
+        gpu_ctx.set_solid_view(0, lobe_rots(0.3))            # the lobe moves, the sphere's own mask stays valid
+        b = check("lobe moved")
+        assert not np.array_equal(np.isnan(a[..., 0]), np.isnan(b[..., 0]))
+        gpu_ctx.set_solid_view(1, np.array([[1.0, 0.2 * PI, 0.6]]))  # now the sphere moves (about an axis off its centre)
+        c = check("sphere moved")
+        assert not np.array_equal(c[..., 0] == 7.5, b[..., 0] == 7.5)
+        gpu_ctx.set_image(480, 360, mg.REFERENCE_BOUNDS)     # another image: both masks stale
+        check("image changed")
+        gpu_ctx.set_image(600, 450, mg.REFERENCE_BOUNDS)
+        bigger = (sphere.reshape(-1, 3) - np.array([1.0, 0, 0])) * 1.6 + np.array([1.0, 0, 0])
+        gpu_ctx.set_solid(1, bigger.reshape(-1, 12), 7.5)    # other geometry in the same slot, same view
+        d = check("geometry changed")
+        assert not np.array_equal(d[..., 0] == 7.5, c[..., 0] == 7.5)
+        gpu_ctx.set_row_tiles(16, 1, 2)                      # a shard of the image: masks are per local row
+        check("sharded")
+        gpu_ctx.set_row_tiles(16, 0, 1)
+        check("whole again")
+    finally:
+        gpu_ctx.set_row_tiles(16, 0, 1)
+        gpu_ctx.set_solid(0, np.zeros((0, 12)))
+        gpu_ctx.set_solid(1, np.zeros((0, 12)))
