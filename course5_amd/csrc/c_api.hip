@@ -71,6 +71,7 @@ struct Solid {
     c5::RotationList seen_rots{};
     c5::ImageParams seen_im{};
     uint64_t generation = 0, seen_generation = ~uint64_t{0};
+    hipStream_t seen_stream = nullptr;  // the own mask is written and read in the order of ONE stream
     int unchanged_frames = 0;
     bool own_mask_ready = false;
 };
@@ -295,8 +296,8 @@ int enqueue_solids(c5_context* ctx, FrameSlot& fs, int slot_id, hipStream_t s, c
         for (int k = 0; k < C5_MAX_SOLIDS; ++k) {
             Solid& so = ctx->solids[k];
             if (so.n_tets <= 0) continue;
-            // unchanged since the frame before?  (one stream only: the cached mask is written and read in stream order)
-            const bool same = ctx->solid_cache && !ctx->pipeline && !ctx->overlap_setup && so.seen_generation == so.generation &&
+            // unchanged since the frame before, and still on the same stream?
+            const bool same = ctx->solid_cache && !ctx->pipeline && so.seen_stream == s && so.seen_generation == so.generation &&
                               same_rotations(so.seen_rots, so.rots) && same_image(so.seen_im, im);
             so.unchanged_frames = same ? so.unchanged_frames + 1 : 0;
             if (!same) {
@@ -304,6 +305,7 @@ int enqueue_solids(c5_context* ctx, FrameSlot& fs, int slot_id, hipStream_t s, c
                 so.seen_rots = so.rots;
                 so.seen_im = im;
                 so.seen_generation = so.generation;
+                so.seen_stream = s;
             }
             if (so.own_mask_ready) {
                 c5::launch_mask_overlay(s, so.own_mask.as<uint32_t>(), fs.mask.as<uint32_t>(), padded);
