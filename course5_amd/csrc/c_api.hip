@@ -122,6 +122,8 @@ struct c5_context {
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     int fuse_setup = 0;     // build_records + entry_raster as one launch of interleaved workgroups: measured 0.119 ms against
                             // 0.047 + 0.047 ms for the two launches on the C3 frame (the raster inherits the records' 49 KB of LDS)
+    int stage_slots = 0;    // "stage_slots": 0 = chosen per frame from rays_per_cell, or 16 / 24
+    double rays_per_cell = 0.0;  // of the last finished frame (0: none yet)
     int solid_cache = 1;    // a solid unchanged since the frame before is not rastered again (enqueue_solids)
     int overlap_setup = 0;  // measured: 1.27 vs 1.26 ms/frame, the side stream buys nothing
     DeviceBuffer px, py, pz, cell_vert, cell_adj, alpha, q, bface;
@@ -530,6 +532,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     wp.max_steps = static_cast<uint32_t>(ctx->n_cells + 64);
     wp.xcd_mode = ctx->xcd_mode;
     wp.lds_pad = ctx->lds_pad;
+    wp.stage_slots = ctx->stage_slots ? ctx->stage_slots : (ctx->rays_per_cell > 0.0 && ctx->rays_per_cell < 120.0 ? 24 : 16);
     wp.band_rows = ctx->band_rows;
     wp.order = ctx->order;
     // walk_composite_lds addresses the records by 32-bit byte offsets: n_cells * 128 must fit
@@ -618,6 +621,13 @@ int finish_frame(c5_context* ctx) {
     }
     c5_stats& st = ctx->last;
     st.segments = static_cast<int64_t>(hc.segments);
+    // How coarse the pixels are against the cells decides how many distinct cells an 8x8 tile meets per step, and
+    // with it how many staging slots the next frame's walk gets (walk_kernels.hip: 16 or 24): rays per cell of the
+    // WHOLE frame, this context's share scaled up by the number of row shards.
+    if (ctx->n_cells > 0 && hc.segments > 0)
+        ctx->rays_per_cell = static_cast<double>(hc.segments) * static_cast<double>(ctx->im.world > 0 ? ctx->im.world : 1) *
+                             (static_cast<double>(ctx->im.res_y) / static_cast<double>(ctx->im.row_count > 0 ? ctx->im.row_count : ctx->im.res_y)) /
+                             static_cast<double>(ctx->n_cells);
     st.covered_pixels = static_cast<int64_t>(hc.covered);
     st.solid_pixels = static_cast<int64_t>(hc.solid_pixels);
     st.entries = static_cast<int64_t>(hc.entries);
@@ -1121,6 +1131,9 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
         ctx->fuse_setup = static_cast<int>(value) != 0;
     } else if (n == "overlap_setup") {
         ctx->overlap_setup = static_cast<int>(value) != 0;
+    } else if (n == "stage_slots") {
+        if (value != 0 && value != 16 && value != 24) return fail(ctx, C5_ERR_INVALID, "stage_slots must be 0 (per frame), 16 or 24");
+        ctx->stage_slots = static_cast<int>(value);
     } else if (n == "solid_cache") {
         ctx->solid_cache = static_cast<int>(value) != 0;
         for (Solid& so : ctx->solids) so.own_mask_ready = false, so.unchanged_frames = 0, so.seen_generation = ~uint64_t{0};

@@ -49,7 +49,8 @@ struct WalkParams {
     uint32_t max_steps;
     int32_t xcd_mode;
     int32_t band_tiles;         // xcd_mode 1: workgroup-tile rows per band (set by launch_walk)
-    int32_t lds_stage;          // 1: walk_composite_lds (records staged through LDS), 0: direct loads
+    int32_t lds_stage;          // 2: walk_composite_lds with LDS-DMA staging, 1: staged through registers, 0: direct loads
+    int32_t stage_slots;        // lds_stage 2: 16 or 24 distinct cells staged per wavefront and step
     int32_t band_rows;          // xcd_mode 1: image rows per band (0: 32)
     int32_t lds_pad;            // tuning: extra dynamic LDS per workgroup (bytes) to cap the resident wavefronts
     int32_t order;              // 0: back to front in the reference's arithmetic; 1: front to back + early-out

@@ -503,8 +503,13 @@ __device__ unsigned long long g_walk_stamps[16];
 #define C5_EMIT_NOW 0
 #endif
 using LdsInts = const __attribute__((address_space(3))) int*;
-template <int TILE, int ORDER, bool DMA = false>
-__global__ __launch_bounds__(256, DMA ? C5_DMA_WAVES : C5_WALK_WAVES) void walk_composite_lds(WalkParams P) {
+// SLOTS: distinct cells staged per wavefront and step (16, or 24 for frames whose pixels are coarse against the
+// cells: more distinct cells per 8x8 tile; 24 slots leave a CU six workgroups instead of seven).  Walk ms with
+// 16 / 24 slots: C3 grid at 1200x900 0.318 / 0.271, C2 ball 0.119 / 0.114, C3 at 2400x1800 0.549 / 0.574, at
+// 4800x3600 1.84 / 1.99 — the host picks by the rays per cell of the frame before (c_api.hip).
+template <int TILE, int ORDER, bool DMA = false, int SLOTS = kStageSlots>
+__global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 6 : C5_DMA_WAVES) : C5_WALK_WAVES) void walk_composite_lds(WalkParams P) {
+    constexpr int kStageSlots = SLOTS;  // (shadows the namespace constant: everything below is per instantiation)
     using TS = TileShape<TILE>;
     constexpr int TW = TS::WW * TS::GX, TH = TS::WH * TS::GY;
     constexpr bool kUp = (ORDER == 0);
@@ -973,7 +978,9 @@ static void launch_walk_t(hipStream_t s, const WalkParams& p) {
         blocks = 8ll * ((n_sb + 7) / 8) * S * S;
         WalkParams q = p;
         q.band_tiles = S;
-        if (p.lds_stage == 2)
+        if (p.lds_stage == 2 && p.stage_slots > 16)
+            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true, 24>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, q);
+        else if (p.lds_stage == 2)
             hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, q);
         else
             hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, q);
@@ -990,7 +997,9 @@ static void launch_walk_t(hipStream_t s, const WalkParams& p) {
         blocks = 8ll * rounds * band * tiles_x;
         WalkParams q = p;
         q.band_tiles = band;
-        if (p.lds_stage == 2)
+        if (p.lds_stage == 2 && p.stage_slots > 16)
+            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true, 24>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, q);
+        else if (p.lds_stage == 2)
             hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, q);
         else if (p.lds_stage)
             hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, q);
@@ -998,7 +1007,9 @@ static void launch_walk_t(hipStream_t s, const WalkParams& p) {
             hipLaunchKernelGGL((walk_composite<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, q);
         return;
     }
-    if (p.lds_stage == 2)
+    if (p.lds_stage == 2 && p.stage_slots > 16)
+        hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true, 24>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, p);
+    else if (p.lds_stage == 2)
         hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, p);
     else if (p.lds_stage)
         hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, p);

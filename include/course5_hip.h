@@ -167,6 +167,9 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  cell record once, straight into LDS (global_load_lds_dwordx4), and its rays read it from there;
  *                  1: the same staged through vector registers (global_load + ds_write_b128; also what 2 falls
  *                  back to beyond 2^24 cells); 0: every lane loads its own record.  Same results, bit for bit.
+ *   "stage_slots"  "lds_stage" 2: distinct cells staged per wavefront and step.  0 (default): 24 when the frame before had
+ *                  fewer than 120 ray-cell segments per cell (pixels coarse against the cells: more distinct cells per
+ *                  8x8 tile), else 16 (one more wavefront per SIMD); 16 / 24: fixed.  Same results either way.
  *   "tile"         wavefront tile: 0 = 64x1 row tile, 1 = 16x4, 2 = 8x8 pixels (default).
  *   "xcd_mode"     how workgroups map to the 8 XCDs (blocks b and b + 8 share an L2): 2 (default): square
  *                  super-blocks of workgroups dealt round-robin; 1: bands of image rows; 0: row-major tiles.

@@ -14,7 +14,8 @@ from course5_amd import capi, meshgen as mg
 from oracle.pyoracle import Oracle
 
 # (lds_stage, integration, tile); the first one is the product default
-VARIANTS = ((2, 0, 2), (1, 0, 0), (2, 1, 2), (0, 0, 1), (2, 0, 1), (0, 1, 0), (1, 1, 1), (2, 0, 0), (1, 0, 2), (2, 1, 1))
+# lds_stage 3 here: LDS-DMA staging with 24 slots ("stage_slots" 24)
+VARIANTS = ((2, 0, 2), (1, 0, 0), (2, 1, 2), (0, 0, 1), (2, 0, 1), (0, 1, 0), (1, 1, 1), (3, 0, 2), (1, 0, 2), (3, 1, 1), (2, 0, 0))
 
 
 def scene(seed):
@@ -60,7 +61,8 @@ def main():
         ctx.set_view(rots)
         ctx.set_alpha_limit(limit)
         for lds, order, tile in VARIANTS:
-            ctx.set_option("lds_stage", lds); ctx.set_option("integration", order); ctx.set_option("tile", tile)
+            ctx.set_option("lds_stage", min(lds, 2)); ctx.set_option("stage_slots", 24 if lds == 3 else 16)
+            ctx.set_option("integration", order); ctx.set_option("tile", tile)
             img = ctx.render(); st = ctx.stats()
             a, b = img.astype(np.float64), ref["image"].astype(np.float64)
             tol = 1e-5 * np.maximum(np.abs(a), np.abs(b)) + 1e-6 * np.abs(b).max()

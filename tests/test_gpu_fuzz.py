@@ -39,7 +39,8 @@ def test_random_scenes_match_the_oracle(gpu_ctx, oracle_port, block):
         gpu_ctx.set_view(rots)
         gpu_ctx.set_alpha_limit(limit)
         lds, order, tile = fuzz.VARIANTS[k % len(fuzz.VARIANTS)]
-        gpu_ctx.set_option("lds_stage", lds)
+        gpu_ctx.set_option("lds_stage", min(lds, 2))
+        gpu_ctx.set_option("stage_slots", 24 if lds == 3 else 16)
         gpu_ctx.set_option("integration", order)
         gpu_ctx.set_option("tile", tile)
         img = gpu_ctx.render()
@@ -59,6 +60,7 @@ def test_random_scenes_match_the_oracle(gpu_ctx, oracle_port, block):
         assert int((np.abs(a - b) > tol).sum()) == 0, ("mixed", seed)
         assert abs(st["segments"] - ref["segments"]) <= max(3, ref["segments"] // 5000), ("mixed", seed)
     gpu_ctx.set_option("lds_stage", 2)
+    gpu_ctx.set_option("stage_slots", 0)
     gpu_ctx.set_option("integration", 0)
     gpu_ctx.set_option("tile", 2)
     gpu_ctx.set_alpha_limit(2.5)
