@@ -84,7 +84,8 @@ size_t segment_bytes();
 void launch_mask_overlay(hipStream_t s, const uint32_t* src, uint32_t* dst, int64_t n_padded);
 
 // walk_kernels.hip
-void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, int order);
+// with_optics: also rebuild the cells' optics (view-independent: only when scalars, alpha limit or order changed)
+void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, int order, bool with_optics);
 void launch_entry_lists(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
                         const ImageParams& im, EntryHead* head, Entry* first, Entry* pool, int64_t capacity,
                         FrameCounters* counters, unsigned* sticky, int want_upper);
@@ -96,7 +97,7 @@ void launch_walk(hipStream_t s, const WalkParams& p, int tile_shape);
 
 // walk_mixed.hip ("precision" 1)
 void launch_build_records_mixed(hipStream_t s, const GridView& g, const ImageParams& im, const double* Xtab,
-                                const double* Ytab, double alpha_limit, int order, double steep_ratio);
+                                const double* Ytab, double alpha_limit, int order, double steep_ratio, bool with_optics);
 void launch_walk_mixed(hipStream_t s, const WalkParams& p, int tile_shape);
 bool mixed_precision_fits(int64_t n_cells, const ImageParams& im);
 

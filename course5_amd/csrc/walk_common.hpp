@@ -44,15 +44,37 @@ __device__ __forceinline__ FacePlane face_plane(const double (&p)[4][3], int f) 
     return r;
 }
 
+template <bool kOptics>
 __device__ __forceinline__ bool build_cell_impl(const GridView& g, double alpha_limit, int order, int64_t cell,
                                                 CellRecord& r, CellOptics& o, double (*verts)[3]);
 // verts (optional): the cell's four transformed vertices
 __device__ __forceinline__ bool build_cell(const GridView& g, double alpha_limit, int order, int64_t cell, CellRecord& r,
                                            CellOptics& o, double (*verts)[3] = nullptr) {
-    return build_cell_impl(g, alpha_limit, order, cell, r, o, verts);
+    return build_cell_impl<true>(g, alpha_limit, order, cell, r, o, verts);
+}
+
+// A cell's optics: its scalars, the alpha limit and the integration order — nothing of the view (line.cpp:204-224).
+// The host has them rebuilt only when one of those changes (c_api.hip: optics_valid), not every frame.
+__device__ __forceinline__ CellOptics cell_optics(const GridView& g, double alpha_limit, int order, int64_t cell) {
+    CellOptics o;
+    const double a_raw = g.alpha[cell];
+    const double qv = g.q[cell];
+    double a_c = a_raw;
+    if (a_c > alpha_limit) a_c = alpha_limit;
+    o.alpha_raw = a_raw;
+    o.q = qv;
+    if (a_c < DBL_EPSILON) {
+        o.alpha_c = 0.0;
+        o.aux = 0.0;
+    } else {
+        o.alpha_c = a_c;
+        o.aux = (order == 0) ? 1.0 / a_c : qv / a_c;
+    }
+    return o;
 }
 
 // Records of one cell; false if the cell is outside this context's row band (nothing to store).
+template <bool kOptics>
 __device__ __forceinline__ bool build_cell_impl(const GridView& g, double alpha_limit, int order, int64_t cell,
                                                 CellRecord& r, CellOptics& o, double (*verts)[3]) {
     const int4 cv = g.cell_vert[cell];
@@ -147,20 +169,7 @@ __device__ __forceinline__ bool build_cell_impl(const GridView& g, double alpha_
     }
     r.nbr[0] |= static_cast<uint32_t>(stored_up) << kUpperCountShift;
 
-    // line.cpp:204-224
-    const double a_raw = g.alpha[cell];
-    const double qv = g.q[cell];
-    double a_c = a_raw;
-    if (a_c > alpha_limit) a_c = alpha_limit;
-    o.alpha_raw = a_raw;
-    o.q = qv;
-    if (a_c < DBL_EPSILON) {
-        o.alpha_c = 0.0;
-        o.aux = 0.0;
-    } else {
-        o.alpha_c = a_c;
-        o.aux = (order == 0) ? 1.0 / a_c : qv / a_c;
-    }
+    if (kOptics) o = cell_optics(g, alpha_limit, order, cell);  // line.cpp:204-224
     return true;
 }
 

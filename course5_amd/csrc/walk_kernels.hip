@@ -35,46 +35,57 @@ struct alignas(16) Q4 {
 constexpr int kRecPad = 9;  // 16-byte units per record in LDS: 8 + 1 pad (conflict-free b128 rows)
 constexpr int kOptPad = 3;  // 2 + 1 pad
 
+// kOptics: also (re)build the cells' optics — of EVERY cell, the ones outside this context's row band included,
+// since they depend on nothing of the view and are not rebuilt until the scalars, the limit or the order change.
+template <bool kOptics>
 __device__ __forceinline__ void build_records_block(const GridView& g, double alpha_limit, int order, unsigned block,
                                                     Q4 (*s_rec)[64 * kRecPad], Q4 (*s_opt)[64 * kOptPad]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t cell = block * static_cast<int64_t>(blockDim.x) + threadIdx.x;
     const int64_t wave_first = cell - lane;
-    bool valid = cell < g.n_cells;
+    const bool in_grid = cell < g.n_cells;
+    bool valid = in_grid;
     CellRecord r;
     CellOptics o;
-    if (valid) valid = build_cell(g, alpha_limit, order, cell, r, o);
+    if (valid) valid = build_cell_impl<false>(g, alpha_limit, order, cell, r, o, nullptr);
     const unsigned long long valid_mask = __builtin_amdgcn_ballot_w64(valid);
-    if (valid_mask == 0ull) return;  // wave-uniform
+    const unsigned long long grid_mask = kOptics ? __builtin_amdgcn_ballot_w64(in_grid) : 0ull;
+    if ((valid_mask | grid_mask) == 0ull) return;  // wave-uniform
     Q4* const my_rec = s_rec[wave];
     Q4* const my_opt = s_opt[wave];
     if (valid) {
         const Q4* rp = reinterpret_cast<const Q4*>(&r);
-        const Q4* op = reinterpret_cast<const Q4*>(&o);
 #pragma unroll
         for (int k = 0; k < 8; ++k) my_rec[lane * kRecPad + k] = rp[k];
+    }
+    if (kOptics && in_grid) {
+        o = cell_optics(g, alpha_limit, order, cell);
+        const Q4* op = reinterpret_cast<const Q4*>(&o);
         my_opt[lane * kOptPad] = op[0];
         my_opt[lane * kOptPad + 1] = op[1];
     }
     __builtin_amdgcn_wave_barrier();
     Q4* const rec_out = reinterpret_cast<Q4*>(g.rec + wave_first);
-    Q4* const opt_out = reinterpret_cast<Q4*>(g.opt + wave_first);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {  // 8 x 1 KiB: records 8k .. 8k+7 of the wavefront
         const int rec_i = k * 8 + (lane >> 3);
         if ((valid_mask >> rec_i) & 1ull) rec_out[k * 64 + lane] = my_rec[rec_i * kRecPad + (lane & 7)];
     }
+    if (kOptics) {
+        Q4* const opt_out = reinterpret_cast<Q4*>(g.opt + wave_first);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {  // 2 x 1 KiB of optics
-        const int opt_i = k * 32 + (lane >> 1);
-        if ((valid_mask >> opt_i) & 1ull) opt_out[k * 64 + lane] = my_opt[opt_i * kOptPad + (lane & 1)];
+        for (int k = 0; k < 2; ++k) {  // 2 x 1 KiB of optics
+            const int opt_i = k * 32 + (lane >> 1);
+            if ((grid_mask >> opt_i) & 1ull) opt_out[k * 64 + lane] = my_opt[opt_i * kOptPad + (lane & 1)];
+        }
     }
 }
 
+template <bool kOptics>
 __global__ __launch_bounds__(256) void build_records(GridView g, double alpha_limit, int order) {
     __shared__ Q4 s_rec[4][64 * kRecPad];
     __shared__ Q4 s_opt[4][64 * kOptPad];
-    build_records_block(g, alpha_limit, order, blockIdx.x, s_rec, s_opt);
+    build_records_block<kOptics>(g, alpha_limit, order, blockIdx.x, s_rec, s_opt);
 }
 
 __global__ __launch_bounds__(256) void entry_raster(GridView g, RasterArgs A) { entry_raster_block(g, A, blockIdx.x); }
@@ -92,13 +103,16 @@ __global__ __launch_bounds__(256) void setup_fused(GridView g, double alpha_limi
     if (raster)
         entry_raster_block(g, A, idx);
     else
-        build_records_block(g, alpha_limit, order, idx, s_rec, s_opt);
+        build_records_block<true>(g, alpha_limit, order, idx, s_rec, s_opt);
 }
 
-void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, int order) {
+void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, int order, bool with_optics) {
     if (g.n_cells <= 0) return;
     const unsigned blocks = static_cast<unsigned>((g.n_cells + 255) / 256);
-    hipLaunchKernelGGL(build_records, dim3(blocks), dim3(256), 0, s, g, alpha_limit, order);
+    if (with_optics)
+        hipLaunchKernelGGL(build_records<true>, dim3(blocks), dim3(256), 0, s, g, alpha_limit, order);
+    else
+        hipLaunchKernelGGL(build_records<false>, dim3(blocks), dim3(256), 0, s, g, alpha_limit, order);
 }
 
 void launch_entry_lists(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,

@@ -44,15 +44,27 @@ struct alignas(16) U4 {
     uint32_t a, b, c, d;
 };
 
+// kOptics: also (re)write the cells' OptRecords — of every cell, whatever the row band (they depend on the scalars
+// and the alpha limit only; the host asks for them when one of those changed, c_api.hip)
+template <bool kOptics>
 __global__ __launch_bounds__(256) void build_records_mixed(GridView g, ImageParams im, const double* __restrict__ Xtab,
                                                            const double* __restrict__ Ytab, double alpha_limit, int order,
                                                            double steep_ratio) {
     const int64_t cell = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
     if (cell >= g.n_cells) return;
+    if (kOptics) {
+        const CellOptics o = cell_optics(g, alpha_limit, order, cell);
+        OptRecord q;
+        q.alpha_raw = static_cast<float>(o.alpha_raw);
+        q.alpha_c = static_cast<float>(o.alpha_c);
+        q.source = (o.alpha_c != 0.0) ? static_cast<float>(o.q / o.alpha_c) : 0.0f;
+        q.pad = 0.0f;
+        *reinterpret_cast<F4*>(g.opt32 + cell) = *reinterpret_cast<const F4*>(&q);
+    }
     CellRecord r;
-    CellOptics o;
+    CellOptics o_unused;
     double v[4][3];
-    if (!build_cell(g, alpha_limit, order, cell, r, o, v)) return;  // outside this context's row band
+    if (!build_cell_impl<false>(g, alpha_limit, order, cell, r, o_unused, v)) return;  // outside this context's row band
 
     // origin: the pixel nearest the centre of the cell's footprint, clamped to the image (a cell outside the
     // domain is never walked)
@@ -126,20 +138,17 @@ __global__ __launch_bounds__(256) void build_records_mixed(GridView g, ImagePara
     U4* dst = reinterpret_cast<U4*>(g.geo + cell);
 #pragma unroll
     for (int k = 0; k < 4; ++k) dst[k] = src[k];
-    OptRecord q;
-    q.alpha_raw = static_cast<float>(o.alpha_raw);
-    q.alpha_c = static_cast<float>(o.alpha_c);
-    q.source = (o.alpha_c != 0.0) ? static_cast<float>(o.q / o.alpha_c) : 0.0f;
-    q.pad = 0.0f;
-    *reinterpret_cast<F4*>(g.opt32 + cell) = *reinterpret_cast<const F4*>(&q);
     g.z0[cell] = z0f;
 }
 
 void launch_build_records_mixed(hipStream_t s, const GridView& g, const ImageParams& im, const double* Xtab,
-                                const double* Ytab, double alpha_limit, int order, double steep_ratio) {
+                                const double* Ytab, double alpha_limit, int order, double steep_ratio, bool with_optics) {
     if (g.n_cells <= 0) return;
     const unsigned blocks = static_cast<unsigned>((g.n_cells + 255) / 256);
-    hipLaunchKernelGGL(build_records_mixed, dim3(blocks), dim3(256), 0, s, g, im, Xtab, Ytab, alpha_limit, order, steep_ratio);
+    if (with_optics)
+        hipLaunchKernelGGL(build_records_mixed<true>, dim3(blocks), dim3(256), 0, s, g, im, Xtab, Ytab, alpha_limit, order, steep_ratio);
+    else
+        hipLaunchKernelGGL(build_records_mixed<false>, dim3(blocks), dim3(256), 0, s, g, im, Xtab, Ytab, alpha_limit, order, steep_ratio);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -167,6 +167,9 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  cell record once, straight into LDS (global_load_lds_dwordx4), and its rays read it from there;
  *                  1: the same staged through vector registers (global_load + ds_write_b128; also what 2 falls
  *                  back to beyond 2^24 cells); 0: every lane loads its own record.  Same results, bit for bit.
+ *   "optics_once"  1 (default): a cell's optics (alpha, clamped alpha, its reciprocal, Q: nothing of the view) are rebuilt
+ *                  only after c5_upload_grid / c5_update_scalars or a change of the alpha limit or "integration", not
+ *                  every frame; 0: every frame.  Same results.
  *   "stage_slots"  "lds_stage" 2: distinct cells staged per wavefront and step.  0 (default): 24 when the frame before had
  *                  fewer than 120 ray-cell segments per cell (pixels coarse against the cells: more distinct cells per
  *                  8x8 tile), else 16 (one more wavefront per SIMD); 16 / 24: fixed.  Same results either way.
