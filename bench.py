@@ -64,7 +64,7 @@ def parse():
     p.add_argument("--mode", choices=["rows", "frames"], default="rows",
                    help="N > 1: rows = every frame is split by rows over the ranks and exchanged (config 4); "
                         "frames = frame k of a sweep is rendered whole by rank k mod N, no exchange (config 5)")
-    p.add_argument("--tile", type=int, default=-1, help="wavefront tile shape override (0: 64x1, 1: 16x4, 2: 8x8)")
+    p.add_argument("--tile", type=int, default=-1, help="wavefront tile shape override (0: 64x1, 1: 16x4, 2: 8x8 in workgroups of four, 3: 8x8 one per workgroup)")
     p.add_argument("--lds-stage", type=int, default=-1, help="override: 2 = LDS-DMA staging (default), 1 = staged through vector registers, 0 = direct loads")
     p.add_argument("--precision", type=int, default=-1, help="override of the \"precision\" option, if the library has it")
     p.add_argument("--pipeline", type=int, default=-1, help="override: overlap the next frame's setup with the walk (1) or not (0)")

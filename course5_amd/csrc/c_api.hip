@@ -157,7 +157,7 @@ struct c5_context {
     // options
     double alpha_limit = 2.5;
     double t_cutoff = 1e-12;
-    int tile_shape = 2;  // 8x8 pixels per wavefront: fewest distinct cells per step
+    int tile_shape = 3;  // 8x8 pixels per wavefront (fewest distinct cells per step), one wavefront per workgroup
     int xcd_mode = 2;
     int lds_pad = 0;
     int band_rows = 0;
@@ -1134,7 +1134,7 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
     if (!ctx || !name) return fail(ctx, C5_ERR_INVALID, "null option");
     const std::string n(name);
     if (n == "tile") {
-        if (value < 0 || value > 2) return fail(ctx, C5_ERR_INVALID, "tile must be 0, 1 or 2");
+        if (value < 0 || value > 3) return fail(ctx, C5_ERR_INVALID, "tile must be 0, 1, 2 or 3");
         ctx->tile_shape = static_cast<int>(value);
     } else if (n == "transmittance_cutoff") {
         ctx->t_cutoff = value;

@@ -187,6 +187,11 @@ template <>
 struct TileShape<2> {  // 8x8 per wavefront; workgroup 16 x 16
     static constexpr int WW = 8, WH = 8, GX = 2, GY = 2;
 };
+template <>
+struct TileShape<3> {  // 8x8 per wavefront, ONE wavefront per workgroup: a wavefront's slot (and its LDS) is free for
+                       // the next tile the moment its own rays are done, not when the slowest of four is
+    static constexpr int WW = 8, WH = 8, GX = 1, GY = 1;
+};
 
 __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
 #pragma unroll

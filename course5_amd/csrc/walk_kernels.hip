@@ -528,10 +528,11 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 6 : C5_DMA_WAVES) : C5_WAL
     constexpr int TW = TS::WW * TS::GX, TH = TS::WH * TS::GY;
     constexpr bool kUp = (ORDER == 0);
     constexpr bool kEmitNow = DMA && C5_EMIT_NOW != 0;
-    __shared__ V2 s_stage[4][kStageSlots * kSlotStride];
+    constexpr int kWaves = TileShape<TILE>::GX * TileShape<TILE>::GY;  // wavefronts per workgroup
+    __shared__ V2 s_stage[kWaves][kStageSlots * kSlotStride];
     // per wavefront: leader tables of kBuckets1 and 64 buckets + the cell id of every slot
-    __shared__ int s_elect[4][kBuckets1 + 128];
-    __shared__ double s_scur[4][64];
+    __shared__ int s_elect[kWaves][kBuckets1 + 128];
+    __shared__ double s_scur[kWaves][64];
 
     const ImageParams& im = P.im;
     const int tiles_x = (im.res_x + TW - 1) / TW;
@@ -976,6 +977,7 @@ template <int TILE, int ORDER>
 static void launch_walk_t(hipStream_t s, const WalkParams& p) {
     using TS = TileShape<TILE>;
     constexpr int TW = TS::WW * TS::GX, TH = TS::WH * TS::GY;
+    constexpr unsigned kThreads = 64u * TS::GX * TS::GY;
     const int tiles_x = (p.im.res_x + TW - 1) / TW;
     const int tiles_y = (p.im.n_local_rows + TH - 1) / TH;
     if (tiles_x <= 0 || tiles_y <= 0) return;
@@ -993,11 +995,11 @@ static void launch_walk_t(hipStream_t s, const WalkParams& p) {
         WalkParams q = p;
         q.band_tiles = S;
         if (p.lds_stage == 2 && p.stage_slots > 16)
-            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true, 24>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, q);
+            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true, 24>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, q);
         else if (p.lds_stage == 2)
-            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, q);
+            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, q);
         else
-            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, q);
+            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, q);
         return;
     } else {
         // ~16 image rows per band (one row of workgroups), but never fewer than 16 bands (2 per XCD) on a short strip
@@ -1012,23 +1014,23 @@ static void launch_walk_t(hipStream_t s, const WalkParams& p) {
         WalkParams q = p;
         q.band_tiles = band;
         if (p.lds_stage == 2 && p.stage_slots > 16)
-            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true, 24>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, q);
+            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true, 24>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, q);
         else if (p.lds_stage == 2)
-            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, q);
+            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, q);
         else if (p.lds_stage)
-            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, q);
+            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, q);
         else
-            hipLaunchKernelGGL((walk_composite<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, q);
+            hipLaunchKernelGGL((walk_composite<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, s, q);
         return;
     }
     if (p.lds_stage == 2 && p.stage_slots > 16)
-        hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true, 24>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, p);
+        hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true, 24>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, p);
     else if (p.lds_stage == 2)
-        hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, p);
+        hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, p);
     else if (p.lds_stage)
-        hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), static_cast<size_t>(p.lds_pad), s, p);
+        hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, p);
     else
-        hipLaunchKernelGGL((walk_composite<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((walk_composite<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, s, p);
 }
 
 void launch_walk(hipStream_t s, const WalkParams& p, int tile_shape) {
@@ -1036,12 +1038,14 @@ void launch_walk(hipStream_t s, const WalkParams& p, int tile_shape) {
         switch (tile_shape) {
             case 1: launch_walk_t<1, 0>(s, p); break;
             case 2: launch_walk_t<2, 0>(s, p); break;
+            case 3: launch_walk_t<3, 0>(s, p); break;
             default: launch_walk_t<0, 0>(s, p); break;
         }
     } else {
         switch (tile_shape) {
             case 1: launch_walk_t<1, 1>(s, p); break;
             case 2: launch_walk_t<2, 1>(s, p); break;
+            case 3: launch_walk_t<3, 1>(s, p); break;
             default: launch_walk_t<0, 1>(s, p); break;
         }
     }

@@ -159,9 +159,10 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) void w
     using TS = TileShape<TILE>;
     constexpr int TW = TS::WW * TS::GX, TH = TS::WH * TS::GY;
     constexpr bool kUp = (ORDER == 0);
-    __shared__ V4F s_stage[4][kMixSlots * kMixStride];
-    __shared__ int s_elect[4][kMixBuckets + 128];  // leader tables of 256 and 64 buckets + the cell id of every slot
-    __shared__ double s_scur[4][64];
+    constexpr int kWaves = TS::GX * TS::GY;  // wavefronts per workgroup
+    __shared__ V4F s_stage[kWaves][kMixSlots * kMixStride];
+    __shared__ int s_elect[kWaves][kMixBuckets + 128];  // leader tables of 256 and 64 buckets + the cell id of every slot
+    __shared__ double s_scur[kWaves][64];
 
     const ImageParams& im = P.im;
     const int tiles_x = (im.res_x + TW - 1) / TW;
@@ -525,7 +526,7 @@ static void launch_mixed_t(hipStream_t s, const WalkParams& p) {
         blocks = 8ll * ((n_sb + 7) / 8) * S * S;
         q.band_tiles = S;
     }
-    hipLaunchKernelGGL((walk_composite_mixed<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(256),
+    hipLaunchKernelGGL((walk_composite_mixed<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(64u * TS::GX * TS::GY),
                        static_cast<size_t>(p.lds_pad), s, q);
 }
 
@@ -534,12 +535,14 @@ void launch_walk_mixed(hipStream_t s, const WalkParams& p, int tile_shape) {
         switch (tile_shape) {
             case 1: launch_mixed_t<1, 0>(s, p); break;
             case 2: launch_mixed_t<2, 0>(s, p); break;
+            case 3: launch_mixed_t<3, 0>(s, p); break;
             default: launch_mixed_t<0, 0>(s, p); break;
         }
     } else {
         switch (tile_shape) {
             case 1: launch_mixed_t<1, 1>(s, p); break;
             case 2: launch_mixed_t<2, 1>(s, p); break;
+            case 3: launch_mixed_t<3, 1>(s, p); break;
             default: launch_mixed_t<0, 1>(s, p); break;
         }
     }

@@ -173,7 +173,8 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *   "stage_slots"  "lds_stage" 2: distinct cells staged per wavefront and step.  0 (default): 24 when the frame before had
  *                  fewer than 120 ray-cell segments per cell (pixels coarse against the cells: more distinct cells per
  *                  8x8 tile), else 16 (one more wavefront per SIMD); 16 / 24: fixed.  Same results either way.
- *   "tile"         wavefront tile: 0 = 64x1 row tile, 1 = 16x4, 2 = 8x8 pixels (default).
+ *   "tile"         wavefront tile: 0 = 64x1 row tile, 1 = 16x4, 2 = 8x8 pixels, four wavefronts per workgroup; 3 (default):
+ *                  8x8 pixels, one wavefront per workgroup (its slot is free again when ITS rays are done).
  *   "xcd_mode"     how workgroups map to the 8 XCDs (blocks b and b + 8 share an L2): 2 (default): square
  *                  super-blocks of workgroups dealt round-robin; 1: bands of image rows; 0: row-major tiles.
  *   "band_rows"    tuning: rows per super-block ("xcd_mode" 2, 0 = default 32) or band (1, default 16).

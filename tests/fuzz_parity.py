@@ -15,7 +15,7 @@ from oracle.pyoracle import Oracle
 
 # (lds_stage, integration, tile); the first one is the product default
 # lds_stage 3 here: LDS-DMA staging with 24 slots ("stage_slots" 24)
-VARIANTS = ((2, 0, 2), (1, 0, 0), (2, 1, 2), (0, 0, 1), (2, 0, 1), (0, 1, 0), (1, 1, 1), (3, 0, 2), (1, 0, 2), (3, 1, 1), (2, 0, 0))
+VARIANTS = ((2, 0, 3), (1, 0, 0), (2, 1, 3), (0, 0, 1), (2, 0, 1), (0, 1, 0), (1, 1, 1), (3, 0, 3), (1, 0, 2), (3, 1, 1), (2, 0, 0), (2, 0, 2), (1, 1, 3), (0, 0, 3))
 
 
 def scene(seed):
@@ -73,7 +73,7 @@ def main():
                       f"S {st['segments']} vs {ref['segments']}, covered {st['covered_pixels']} vs {ref['covered']}, "
                       f"cells {len(cells)} res {res}", flush=True)
         # option "precision" 1 on the same scene: same bar for the image, the count may differ by grazing rays
-        ctx.set_option("lds_stage", 2); ctx.set_option("tile", 2)
+        ctx.set_option("lds_stage", 2); ctx.set_option("tile", 3)
         for order in (0, 1):
             ctx.set_option("integration", order); ctx.set_option("precision", 1)
             img = ctx.render(); st = ctx.stats()
@@ -90,7 +90,7 @@ def main():
         # cyclic row tiles and contiguous blocks, random world size and tile height, product-default kernel
         from course5_amd import sharding
         rng = np.random.default_rng(seed + 77)
-        ctx.set_option("lds_stage", 2); ctx.set_option("integration", 0); ctx.set_option("tile", 2)
+        ctx.set_option("lds_stage", 2); ctx.set_option("integration", 0); ctx.set_option("tile", 3)
         ctx.set_row_tiles(0, 0, 1)
         ctx.set_row_range(0, -1)
         full = ctx.render()

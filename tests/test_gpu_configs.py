@@ -25,7 +25,7 @@ def c3(gpu_ctx):
     xyz, cells, alpha, q = mg.workload("c3")
     for k in range(8):
         gpu_ctx.set_solid(k, np.zeros((0, 12)))
-    for name, v in (("tile", 2), ("integration", 0), ("lds_stage", 2), ("algorithm", 0), ("xcd_mode", 2)):
+    for name, v in (("tile", 3), ("integration", 0), ("lds_stage", 2), ("algorithm", 0), ("xcd_mode", 2)):
         gpu_ctx.set_option(name, v)
     gpu_ctx.set_row_range(0, -1)
     gpu_ctx.set_row_tiles(0, 0, 1)

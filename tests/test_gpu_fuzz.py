@@ -62,5 +62,5 @@ def test_random_scenes_match_the_oracle(gpu_ctx, oracle_port, block):
     gpu_ctx.set_option("lds_stage", 2)
     gpu_ctx.set_option("stage_slots", 0)
     gpu_ctx.set_option("integration", 0)
-    gpu_ctx.set_option("tile", 2)
+    gpu_ctx.set_option("tile", 3)
     gpu_ctx.set_alpha_limit(2.5)

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 def _mixed(gpu_ctx):
     for k in range(8):
         gpu_ctx.set_solid(k, np.zeros((0, 12)))
-    for name, v in (("tile", 2), ("integration", 0), ("lds_stage", 2), ("algorithm", 0), ("xcd_mode", 2), ("precision", 1)):
+    for name, v in (("tile", 3), ("integration", 0), ("lds_stage", 2), ("algorithm", 0), ("xcd_mode", 2), ("precision", 1)):
         gpu_ctx.set_option(name, v)
     if os.environ.get("C5_STEEP_RATIO"):  # margin probe: how far can the fp64 fall-back threshold go
         gpu_ctx.set_option("steep_ratio", float(os.environ["C5_STEEP_RATIO"]))
@@ -27,7 +27,7 @@ def _mixed(gpu_ctx):
     yield
     gpu_ctx.set_option("precision", 0)
     gpu_ctx.set_option("integration", 0)
-    gpu_ctx.set_option("tile", 2)
+    gpu_ctx.set_option("tile", 3)
 
 
 def _render(ctx, rots, rx, ry, bounds=mg.REFERENCE_BOUNDS, alpha_limit=2.5):
@@ -53,7 +53,7 @@ def test_golden_vectors_mixed(gpu_ctx, path, integration):
     stride = int(fx["stride"])
     gpu_ctx.upload_grid(fx["xyz"], fx["cells"], fx["alpha"], fx["q"])
     for k in range(len(fx["views"])):
-        for tile in (0, 1, 2):
+        for tile in (0, 1, 2, 3):
             gpu_ctx.set_option("tile", tile)
             img, st = _render(gpu_ctx, fx[f"rots{k}"], rx, ry, fx["bounds"], float(fx["alpha_limit"]))
             r = assert_images_match(img[::stride, ::stride], fx[f"image{k}"], f"{fx['name']} view {k} tile {tile}")
@@ -73,7 +73,7 @@ def test_random_scenes_mixed_vs_oracle(gpu_ctx, oracle_port, seed):
     rots = mg.view_rotations(rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-1, 1))
     limit = float(rng.uniform(1, 200))
     rx, ry = int(rng.integers(50, 700)), int(rng.integers(40, 500))
-    gpu_ctx.set_option("tile", seed % 3)
+    gpu_ctx.set_option("tile", seed % 4)
     gpu_ctx.set_option("integration", seed % 2)
     gpu_ctx.upload_grid(xyz, cells, alpha, q)
     img, st = _render(gpu_ctx, rots, rx, ry, alpha_limit=limit)
