@@ -98,6 +98,9 @@ constexpr size_t kCountersBytes = sizeof(c5::FrameCounters) * c5::kCounterShards
 // while walk_composite of frame k (VALU / address-path bound) runs on the main stream.
 struct FrameSlot {
     DeviceBuffer vx, vy, vz, rec, opt, count, head, first, pool, mask, counters, row_cost;
+    DeviceBuffer sb;        // cost of the walk's rows of super-blocks in the last frame (WalkParams::sb_cost)
+    long long sb_key = -1;  // the tiling they belong to (-1: not collected)
+    int sb_n = 0;
     DeviceBuffer geo, opt32, z0;  // "precision" 1: compact records (allocated on first use)
     int64_t entry_capacity = 0;
     bool head_clean = false;  // the per-pixel entry heads are all zero (the walk kernels leave them so)
@@ -127,6 +130,11 @@ struct c5_context {
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     int fuse_setup = 0;     // build_records + entry_raster as one launch of interleaved workgroups: measured 0.119 ms against
                             // 0.047 + 0.047 ms for the two launches on the C3 frame (the raster inherits the records' 49 KB of LDS)
+    int cost_order = 1;     // "cost_order": rows of super-blocks start dearest first (by the last frame the host waited for)
+    uint8_t sb_order[128] = {};
+    long long sb_order_key = -1;
+    int sb_order_n = 0;
+    uint32_t* host_sb = nullptr;  // pinned: the last frame's per-row costs
     int optics_once = 1;    // "optics_once": the cells' optics are rebuilt only when scalars, limit or order changed
     int stage_slots = 0;    // "stage_slots": 0 = chosen per frame from rays_per_cell, or 16 / 24
     double rays_per_cell = 0.0;  // of the last finished frame (0: none yet)
@@ -450,8 +458,28 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
 
     // (a2) view transform
     // (a2) + the frame's statistics cleared by the same launch
+    // + the walk's per-row costs cleared (what decides the order its rows of super-blocks start in, below)
+    uint32_t* sb = nullptr;
+    int n_sb = 0;
+    long long sb_key = -1;
+    if (ctx->cost_order && ctx->xcd_mode == 2 && ctx->lds_stage && im.n_local_rows > 0) {
+        const int sb_rows = c5::walk_sb_rows(ctx->tile_shape, ctx->band_rows);
+        n_sb = (im.n_local_rows + sb_rows - 1) / sb_rows;
+        if (n_sb <= c5::kMaxSbRows) {
+            if (!fs.sb.ptr) {
+                C5_HIP(ctx, fs.sb.ensure(c5::kMaxSbRows * sizeof(uint32_t)));
+                C5_HIP(ctx, hipMemsetAsync(fs.sb.ptr, 0, fs.sb.bytes, s));
+            }
+            sb_key = (static_cast<long long>(im.n_local_rows) << 20) ^ (static_cast<long long>(sb_rows) << 4) ^ ctx->tile_shape;
+            sb = fs.sb.as<uint32_t>();
+        } else {
+            n_sb = 0;
+        }
+    }
+    fs.sb_key = sb_key;
+    fs.sb_n = n_sb;
     c5::launch_transform_soa(s, g.px, g.py, g.pz, g.vx, g.vy, g.vz, g.n_pts, ctx->view,
-                             fs.counters.as<c5::FrameCounters>());
+                             fs.counters.as<c5::FrameCounters>(), sb, n_sb);
     C5_HIP(ctx, mark(1, s));
     const bool bin_sort = ctx->algorithm == 1 || !ctx->grid_conforming;
     if (bin_sort) return enqueue_bin_sort(ctx, fs, g, slot_id, out_dev, s, main_s, timed);
@@ -557,6 +585,12 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     wp.lds_stage = (ctx->lds_stage && ctx->n_cells < (int64_t{1} << 25)) ? ((ctx->lds_stage == 2 && ctx->n_cells < (int64_t{1} << 24)) ? 2 : 1) : 0;
     wp.counters = fs.counters.as<c5::FrameCounters>();
     wp.row_cost = nullptr;
+    wp.sb_cost = sb;
+    wp.n_sb_rows = 0;
+    if (sb && ctx->sb_order_key == sb_key && ctx->sb_order_n == n_sb) {  // an order worked out for this very tiling
+        wp.n_sb_rows = n_sb;
+        std::memcpy(wp.sb_order, ctx->sb_order, sizeof wp.sb_order);
+    }
     wp.sticky = ctx->sticky.as<unsigned>();
     if (ctx->row_costs && im.n_local_rows > 0) {
         wp.row_cost = fs.row_cost.as<uint32_t>();
@@ -612,6 +646,8 @@ int wait_and_collect(c5_context* ctx) {
         FrameSlot& fs = ctx->slots[ctx->last_slot];
         C5_HIP(ctx, hipMemcpyAsync(fs.host_counters, fs.counters.ptr, kCountersBytes, hipMemcpyDeviceToHost, ctx->stream));
         C5_HIP(ctx, hipMemcpyAsync(ctx->host_sticky, ctx->sticky.ptr, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        if (fs.sb_key >= 0 && fs.sb.ptr && ctx->host_sb)
+            C5_HIP(ctx, hipMemcpyAsync(ctx->host_sb, fs.sb.ptr, c5::kMaxSbRows * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         ctx->counters_on_host = true;
     }
     C5_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -637,6 +673,27 @@ int finish_frame(c5_context* ctx) {
         hc.pool_used += p.pool_used;
     }
     c5_stats& st = ctx->last;
+    // The order the next frames' rows of super-blocks start in.  A frame with fewer wavefronts of rays than about two
+    // rounds of the GPU's wavefront slots lasts as long as its longest wavefronts plus the time the dispatcher takes
+    // to reach them behind thousands of empty or short tiles: such frames start their rows dearest first (by this
+    // frame's cost per row, in eight classes of the dearest row's so that rows of about the same cost keep their
+    // image order: C2 ball 0.112 -> 0.098 ms).  Larger frames (several rounds of wavefronts) lose a little that way
+    // (C3 frame 0.540 -> 0.551 ms: every slot starts a full-length ray at once) and stay in image order.
+    ctx->sb_order_key = -1;
+    ctx->sb_order_n = 0;
+    constexpr unsigned long long kSmallFrameRays = 2ull * 256 * 28 * 64;  // two rounds of 7 wavefronts per SIMD
+    if (fs.sb_key >= 0 && ctx->host_sb && fs.sb_n > 1 && fs.sb_n <= c5::kMaxSbRows && hc.covered > 0 && hc.covered < kSmallFrameRays) {
+        const int n = fs.sb_n;
+        uint32_t top = 0;
+        for (int j = 0; j < n; ++j) top = std::max(top, ctx->host_sb[j]);
+        const uint32_t unit = top / 8u + 1u;
+        int order[c5::kMaxSbRows];
+        for (int j = 0; j < n; ++j) order[j] = j;
+        std::stable_sort(order, order + n, [&](int a, int b) { return ctx->host_sb[a] / unit > ctx->host_sb[b] / unit; });
+        for (int j = 0; j < n; ++j) ctx->sb_order[j] = static_cast<uint8_t>(order[j]);
+        ctx->sb_order_key = fs.sb_key;
+        ctx->sb_order_n = n;
+    }
     st.segments = static_cast<int64_t>(hc.segments);
     // How coarse the pixels are against the cells decides how many distinct cells an 8x8 tile meets per step, and
     // with it how many staging slots the next frame's walk gets (walk_kernels.hip: 16 or 24): rays per cell of the
@@ -792,6 +849,10 @@ int c5_create(int device_ordinal, c5_context** out_ctx) {
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->host_sticky), 2 * sizeof(unsigned), hipHostMallocDefault)) != hipSuccess)
         return bail(e, "hipHostMalloc");
     ctx->host_sticky[0] = ctx->host_sticky[1] = 0;
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->host_sb), c5::kMaxSbRows * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
+        ctx->host_sb = nullptr;  // (the walk then starts its rows in image order)
+    else
+        std::memset(ctx->host_sb, 0, c5::kMaxSbRows * sizeof(uint32_t));
     ctx->view.n = 0;
     for (Solid& s : ctx->solids) s.rots.n = 0;
     *out_ctx = ctx;
@@ -807,10 +868,11 @@ void c5_destroy(c5_context* ctx) {
                             &ctx->q, &ctx->bface, &ctx->xtab, &ctx->ytab, &ctx->out, &ctx->sticky,
                             &ctx->offs64, &ctx->scratch64, &ctx->segs};
     if (ctx->host_sticky) (void)hipHostFree(ctx->host_sticky);
+    if (ctx->host_sb) (void)hipHostFree(ctx->host_sb);
     for (DeviceBuffer* b : bufs) b->release();
     for (FrameSlot& fs : ctx->slots) {
         DeviceBuffer* sb[] = {&fs.vx, &fs.vy, &fs.vz, &fs.rec, &fs.opt, &fs.count, &fs.head, &fs.first, &fs.pool,
-                              &fs.mask, &fs.counters, &fs.row_cost, &fs.geo, &fs.opt32, &fs.z0};
+                              &fs.mask, &fs.counters, &fs.row_cost, &fs.geo, &fs.opt32, &fs.z0, &fs.sb};
         for (DeviceBuffer* b : sb) b->release();
         if (fs.host_counters) (void)hipHostFree(fs.host_counters);
         for (auto& ev : fs.ev)
@@ -1150,6 +1212,8 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
         ctx->fuse_setup = static_cast<int>(value) != 0;
     } else if (n == "overlap_setup") {
         ctx->overlap_setup = static_cast<int>(value) != 0;
+    } else if (n == "cost_order") {
+        ctx->cost_order = static_cast<int>(value) != 0;
     } else if (n == "optics_once") {
         ctx->optics_once = static_cast<int>(value) != 0;
     } else if (n == "stage_slots") {

@@ -43,8 +43,10 @@ __global__ __launch_bounds__(256) void transform_points_soa(const double* __rest
                                                             double* __restrict__ vx,
                                                             double* __restrict__ vy,
                                                             double* __restrict__ vz, int64_t n,
-                                                            RotationList R, uint32_t* __restrict__ counters) {
+                                                            RotationList R, uint32_t* __restrict__ counters,
+                                                            uint32_t* __restrict__ sb, int n_sb) {
     const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (sb && i < n_sb) sb[i] = 0u;  // the walk's per-row costs of the frame before (read by the host when it waited)
     // first kernel of a frame: it also clears the frame's statistics (one API call less per frame than a
     // memset of its own); the grid covers at least kCountersDwords threads
     if (counters && i < kCountersDwords) counters[i] = 0u;
@@ -496,12 +498,13 @@ size_t segment_bytes() { return sizeof(Segment); }
 
 void launch_transform_soa(hipStream_t s, const double* px, const double* py, const double* pz,
                           double* vx, double* vy, double* vz, int64_t n, const RotationList& R,
-                          FrameCounters* counters_to_clear) {
-    const int64_t threads = counters_to_clear ? (n > kCountersDwords ? n : kCountersDwords) : n;
+                          FrameCounters* counters_to_clear, uint32_t* sb, int n_sb) {
+    int64_t threads = counters_to_clear ? (n > kCountersDwords ? n : kCountersDwords) : n;
+    if (sb && threads < 256) threads = 256;
     if (threads <= 0) return;
     const unsigned blocks = static_cast<unsigned>((threads + 255) / 256);
     hipLaunchKernelGGL(transform_points_soa, dim3(blocks), dim3(256), 0, s, px, py, pz, vx, vy, vz, n, R,
-                       reinterpret_cast<uint32_t*>(counters_to_clear));
+                       reinterpret_cast<uint32_t*>(counters_to_clear), sb, n_sb);
 }
 
 void launch_transform_aos(hipStream_t s, const double* in, double* out, int64_t n,

@@ -55,15 +55,26 @@ struct WalkParams {
     int32_t lds_pad;            // tuning: extra dynamic LDS per workgroup (bytes) to cap the resident wavefronts
     int32_t order;              // 0: back to front in the reference's arithmetic; 1: front to back + early-out
     FrameCounters* counters;
+    // rows of super-blocks (xcd_mode 2) start in the order of their cost in an earlier frame, dearest first (a launch
+    // ends with its last wavefronts: let those be short ones): sb_order[k] = the k-th row to start, n_sb_rows of
+    // them (0: image order); every wavefront adds its segments to sb_cost[its row] (nullptr: not collected).  The
+    // order is worked out by the host whenever it waits for a frame anyway (c_api.hip), and travels as a kernel argument.
+    uint32_t* sb_cost;
+    int32_t n_sb_rows;
+    uint8_t sb_order[128];
     uint32_t* row_cost;         // [n_local_rows] segments per row of this frame, or nullptr
     unsigned* sticky;           // [0] largest entry total, [1] rays over the step bound; reset by the host only
 };
 
 // exact_kernels.hip (-ffp-contract=off)
 // counters_to_clear: the frame's FrameCounters[kCounterShards], zeroed by the same launch (or nullptr)
+// sb_cost_to_clear: the walk's per-row costs (WalkParams::sb_cost), n_sb of them, cleared by the same launch
 void launch_transform_soa(hipStream_t s, const double* px, const double* py, const double* pz,
                           double* vx, double* vy, double* vz, int64_t n, const RotationList& R,
-                          FrameCounters* counters_to_clear);
+                          FrameCounters* counters_to_clear, uint32_t* sb_cost_to_clear = nullptr, int n_sb = 0);
+constexpr int kMaxSbRows = 128;
+// image rows per super-block row of the walk's xcd_mode 2 launch
+int walk_sb_rows(int tile_shape, int band_rows);
 void launch_transform_aos(hipStream_t s, const double* in, double* out, int64_t n,
                           const RotationList& R);
 void launch_solid_mask_raster(hipStream_t s, const double* pts, const int4* faces, int64_t n_faces,

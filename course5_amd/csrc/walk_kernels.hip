@@ -551,7 +551,9 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 6 : C5_DMA_WAVES) : C5_WAL
         const int sb = (seq / (S * S)) * 8 + xcd;
         const int within = seq - (seq / (S * S)) * (S * S);
         if (sb >= sbx_n * sby_n) return;
-        const int sby = sb / sbx_n, sbx = sb - sby * sbx_n;
+        int sby = sb / sbx_n;
+        const int sbx = sb - sby * sbx_n;
+        if (P.n_sb_rows == sby_n) sby = static_cast<int>(P.sb_order[sby]);  // dearest rows first (kernel argument)
         ty = sby * S + within / S;
         tx = sbx * S + (within - (within / S) * S);
         if (tx >= tiles_x || ty >= tiles_y) return;
@@ -950,6 +952,10 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 6 : C5_DMA_WAVES) : C5_WAL
     const unsigned s_ent = wave_sum_u32(n_entries);
     if (lane == 0) {
         FrameCounters* const fc = P.counters + ((blockIdx.x * 4u + static_cast<unsigned>(wave)) % kCounterShards);
+        if (s_seg && P.sb_cost && P.xcd_mode == 2) {  // what this wavefront cost, to its row of super-blocks
+            const int sb_row = ty / P.band_tiles;
+            if (sb_row < kMaxSbRows) atomicAdd(P.sb_cost + sb_row, s_seg);
+        }
         if (s_ent) atomicAdd(&fc->entries, static_cast<unsigned long long>(s_ent));
         if (s_seg) atomicAdd(&fc->segments, static_cast<unsigned long long>(s_seg));
         if (n_step_wave) atomicAdd(&fc->steps, static_cast<unsigned long long>(n_step_wave));
@@ -1031,6 +1037,16 @@ static void launch_walk_t(hipStream_t s, const WalkParams& p) {
         hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, p);
     else
         hipLaunchKernelGGL((walk_composite<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, s, p);
+}
+
+int walk_sb_rows(int tile_shape, int band_rows) {
+    const int th = tile_shape == 0 ? TileShape<0>::WH * TileShape<0>::GY
+                   : tile_shape == 1 ? TileShape<1>::WH * TileShape<1>::GY
+                   : tile_shape == 2 ? TileShape<2>::WH * TileShape<2>::GY
+                                     : TileShape<3>::WH * TileShape<3>::GY;
+    const int sb_rows = band_rows > 0 ? band_rows : 32;
+    const int S = sb_rows / th > 0 ? sb_rows / th : 1;
+    return S * th;
 }
 
 void launch_walk(hipStream_t s, const WalkParams& p, int tile_shape) {

@@ -180,7 +180,9 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) void w
         const int sb = (seq / (S * S)) * 8 + xcd;
         const int within = seq - (seq / (S * S)) * (S * S);
         if (sb >= sbx_n * sby_n) return;
-        const int sby = sb / sbx_n, sbx = sb - sby * sbx_n;
+        int sby = sb / sbx_n;
+        const int sbx = sb - sby * sbx_n;
+        if (P.n_sb_rows == sby_n) sby = static_cast<int>(P.sb_order[sby]);  // dearest rows first (walk_kernels.hip)
         ty = sby * S + within / S;
         tx = sbx * S + (within - (within / S) * S);
         if (tx >= tiles_x || ty >= tiles_y) return;
@@ -496,6 +498,10 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) void w
     const unsigned s_ent = wave_sum_u32(n_entries);
     if (lane == 0) {
         FrameCounters* const fc = P.counters + ((blockIdx.x * 4u + static_cast<unsigned>(wave)) % kCounterShards);
+        if (s_seg && P.sb_cost && P.xcd_mode != 0) {  // what this wavefront cost, to its row of super-blocks
+            const int sb_row = ty / P.band_tiles;
+            if (sb_row < kMaxSbRows) atomicAdd(P.sb_cost + sb_row, s_seg);
+        }
         if (s_ent) atomicAdd(&fc->entries, static_cast<unsigned long long>(s_ent));
         if (s_seg) atomicAdd(&fc->segments, static_cast<unsigned long long>(s_seg));
         if (n_step_wave) atomicAdd(&fc->steps, static_cast<unsigned long long>(n_step_wave));

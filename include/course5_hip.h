@@ -167,6 +167,9 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  cell record once, straight into LDS (global_load_lds_dwordx4), and its rays read it from there;
  *                  1: the same staged through vector registers (global_load + ds_write_b128; also what 2 falls
  *                  back to beyond 2^24 cells); 0: every lane loads its own record.  Same results, bit for bit.
+ *   "cost_order"   1 (default): frames with fewer rays than about two rounds of the GPU's wavefront slots start the rows of
+ *                  their image dearest first (by the cost per row of the last frame the caller waited for) instead
+ *                  of top to bottom; 0: always top to bottom.  Same results.
  *   "optics_once"  1 (default): a cell's optics (alpha, clamped alpha, its reciprocal, Q: nothing of the view) are rebuilt
  *                  only after c5_upload_grid / c5_update_scalars or a change of the alpha limit or "integration", not
  *                  every frame; 0: every frame.  Same results.
