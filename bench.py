@@ -81,9 +81,10 @@ def parse():
     p.add_argument("--no-steady", action="store_true", help="skip the clock-steadying frames after the W warm-up steps (profiling passes)")
     p.add_argument("--cpu-sample-res", default="", help="image size of the CPU baseline (default: the benchmark's own)")
     p.add_argument("--pipeline-depth", type=int, default=2, help="N > 1: frames whose exchange may be in flight")
-    p.add_argument("--sharding", choices=["blocks", "cyclic"], default="cyclic",
-                   help="N > 1: cyclic 16-row tiles (default: every rank renders AND sends 1/N of the image) or "
-                        "contiguous cost-balanced row blocks (received at their final offset, no reassembly)")
+    p.add_argument("--sharding", choices=["blocks", "cyclic"], default="blocks",
+                   help="N > 1: contiguous cost-balanced row blocks (default: every block is received at its final offset "
+                        "of rank 0's frame, no reassembly pass; every rank builds only the records its rays can reach) or "
+                        "cyclic 16-row tiles (one gather of padded strips + a reassembly pass on rank 0)")
     p.add_argument("--row-base-cost", type=float, default=6.0,
                    help="blocks: fixed cost per pixel in segment units added when balancing (measured: an empty "
                         "pixel costs about six segments)")

@@ -10,7 +10,9 @@ Two row layouts:
           construction, but every rank touches the whole grid, so the per-view setup is replicated;
   blocks  one contiguous block per rank (c5_set_row_range), sized by measured per-row cost
           (sharding.balanced_blocks): each rank builds only the records its rays can reach, which
-          shards the per-view setup as well.
+          shards the per-view setup as well.  A block is contiguous in the image, so rank 0 RECEIVES every
+          block at its final offset (one irecv per rank straight into a view of the frame, its own block
+          rendered in place): no gather into staging parts, no reassembly pass over the image.
 """
 from __future__ import annotations
 
@@ -49,9 +51,16 @@ class FramePipeline:
         self.frame = None
         self.parts = None
         self.row_index = None
+        self.frames = None
+        # blocks, exchanged on the device (or between CPU tensors): point-to-point, received in place
+        self.in_place = world > 1 and self.blocks is not None and not host_staging
         if world > 1 and rank == 0:
-            self.parts = [[torch.empty_like(self.strips[0]) for _ in range(world)] for _ in range(self.depth)]
-            self.frame = torch.empty((res_y, res_x, 2), dtype=torch.float32, device=device)
+            if self.in_place:
+                self.frames = [torch.empty((res_y, res_x, 2), dtype=torch.float32, device=device) for _ in range(self.depth)]
+                self.frame = self.frames[0]
+            else:
+                self.parts = [[torch.empty_like(self.strips[0]) for _ in range(world)] for _ in range(self.depth)]
+                self.frame = torch.empty((res_y, res_x, 2), dtype=torch.float32, device=device)
             if self.blocks is None:
                 self.row_index = [torch.from_numpy(sharding.local_rows(res_y, tile_rows, r, world)).to(device)
                                   for r in range(world)]
@@ -74,6 +83,11 @@ class FramePipeline:
 
     def _finish(self, slot):
         work, s = slot
+        if self.in_place:
+            work.wait()  # on GPU: the current stream waits for the transfers, the host does not
+            if self.rank == 0:
+                self.frame = self.frames[s]
+            return
         if self.side is None:
             work.wait()  # on GPU: the current stream waits for the collective, the host does not
             if self.rank == 0:
@@ -95,19 +109,31 @@ class FramePipeline:
         if self.assembled[s] is not None:  # the gather of this step overwrites parts[s]
             torch.cuda.current_stream().wait_event(self.assembled[s])
             self.assembled[s] = None
-        render(self.strips[s])
+        # blocks received in place: rank 0 renders its own block straight into the frame
+        target = self.strips[s]
+        if self.in_place and self.rank == 0:
+            b0, n0 = self.blocks[0]
+            target = self.frames[s][b0:b0 + n0]
+        render(target)
         if self.check is not None:
             for _ in range(4):
                 if self.check() == 0:
                     break
                 self.retries += 1
-                render(self.strips[s])
+                render(target)
             else:
                 raise RuntimeError("a frame kept being reported incomplete (C5_RETRY)")
         if self.world == 1:
             self.frame = self.strips[s]
             return
-        if self.host_staging:
+        if self.in_place:
+            if self.rank == 0:
+                ops = [dist.P2POp(dist.irecv, self.frames[s][b:b + n], r) for r, (b, n) in enumerate(self.blocks) if r != 0 and n > 0]
+            else:
+                n = self.blocks[self.rank][1]
+                ops = [dist.P2POp(dist.isend, self.strips[s][:n], 0)] if n > 0 else []
+            work = _All(dist.batch_isend_irecv(ops)) if ops else _Done()
+        elif self.host_staging:
             torch.cuda.current_stream().synchronize()
             host = self.strips[s].cpu()
             got = [torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
@@ -132,6 +158,18 @@ class FramePipeline:
 
 class _Done:
     def wait(self):
+        return True
+
+
+class _All:
+    """The transfers of one step (dist.batch_isend_irecv) as one thing to wait for."""
+
+    def __init__(self, works):
+        self.works = list(works)
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
         return True
 
 
