@@ -135,6 +135,7 @@ struct c5_context {
     long long sb_order_key = -1;
     int sb_order_n = 0;
     uint32_t* host_sb = nullptr;  // pinned: the last frame's per-row costs
+    int entry_key = 1;      // "entry_key": 1 = entries keyed a slack behind their face (hanging-node interfaces), 0 = at the face (testing)
     int optics_once = 1;    // "optics_once": the cells' optics are rebuilt only when scalars, limit or order changed
     int stage_slots = 0;    // "stage_slots": 0 = chosen per frame from rays_per_cell, or 16 / 24
     double rays_per_cell = 0.0;  // of the last finished frame (0: none yet)
@@ -529,6 +530,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     const bool fused = !mixed && ctx->fuse_setup && !side && g.n_cells > 0;
     if (!fused) C5_HIP(ctx, mark(2, s));
     // boundary entries: one raster pass (per-pixel count + first entry + overflow chain)
+    const double key_floor = !ctx->entry_key ? -1.0 : (mixed ? c5::kEntryKeyFloorMixed : c5::kEntryKeyFloor);
     if (!fs.head_clean) C5_HIP(ctx, hipMemsetAsync(fs.head.ptr, 0, static_cast<size_t>(padded) * sizeof(c5::EntryHead), e));
     fs.head_clean = false;
     if (fused) {
@@ -536,12 +538,17 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
         // time of both and ms_entries is zero)
         c5::launch_setup_fused(s, g, ctx->alpha_limit, ctx->order, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im,
                                fs.head.as<c5::EntryHead>(), fs.first.as<c5::Entry>(), fs.pool.as<c5::Entry>(), fs.entry_capacity,
-                               fs.counters.as<c5::FrameCounters>(), ctx->sticky.as<unsigned>(), ctx->order != 0);
+                               fs.counters.as<c5::FrameCounters>(), ctx->sticky.as<unsigned>(), ctx->order != 0, key_floor);
+        // (the fused launch rewrites every cell's optics for the current limit and order)
+        fs.optics_valid = true;
+        fs.optics_limit = ctx->alpha_limit;
+        fs.optics_order = ctx->order;
         C5_HIP(ctx, mark(2, s));
     } else if (g.n_cells > 0) {
         c5::launch_entry_lists(e, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im, fs.head.as<c5::EntryHead>(),
                                fs.first.as<c5::Entry>(), fs.pool.as<c5::Entry>(), fs.entry_capacity,
-                               fs.counters.as<c5::FrameCounters>(), ctx->sticky.as<unsigned>(), ctx->order != 0);
+                               fs.counters.as<c5::FrameCounters>(), ctx->sticky.as<unsigned>(), ctx->order != 0,
+                               key_floor);
     }
     C5_HIP(ctx, mark(3, e));
     // (a9) solids
@@ -1214,6 +1221,8 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
         ctx->overlap_setup = static_cast<int>(value) != 0;
     } else if (n == "cost_order") {
         ctx->cost_order = static_cast<int>(value) != 0;
+    } else if (n == "entry_key") {
+        ctx->entry_key = static_cast<int>(value) != 0;
     } else if (n == "optics_once") {
         ctx->optics_once = static_cast<int>(value) != 0;
     } else if (n == "stage_slots") {

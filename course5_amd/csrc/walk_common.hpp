@@ -273,6 +273,17 @@ __device__ __forceinline__ EntryHead load_entry_head(const EntryHead* p) {
 
 // next place the ray enters the grid beyond s_cur (s = z walking down, -z walking up); -1 if none.
 // The pixel's entries are first[lp] and the chain through the overflow pool (entry_raster).
+//
+// An entry's `z` is a depth KEY, not the entry face's depth: entry_raster pushes it a tolerance (entry_key_slack,
+// below) along the walk, INTO the cell the face belongs to.  Where two cells meet at faces that do not match
+// (hanging nodes: a coarse face against several fine ones — conforming in space, not in connectivity; the
+// reference never looks at connectivity, object3d_base.cpp:37-42 + plane.cpp:184-192 + line.cpp:138) both faces
+// are boundary faces, the ray leaves through one and has to enter through the other AT THE SAME DEPTH — the same
+// plane evaluated from two different vertex triples, equal only to rounding.  With the face's own depth as the
+// key the strict comparison below is a coin toss per crossing, and a lost toss loses the rest of the ray.  With
+// the key pushed into the cell, "the nearest key beyond where the ray left the grid" finds the abutting cell
+// whichever way the rounding fell, and never an entry already used: s_cur is moved to the key taken, and keys
+// are compared strictly.
 template <bool kUp>
 __device__ __forceinline__ int next_entry(const WalkParams& P, size_t lp, EntryHead h, double& s_cur) {
     double s_best = -DBL_MAX;
@@ -307,6 +318,22 @@ __device__ __forceinline__ int next_entry(const WalkParams& P, size_t lp, EntryH
 // (count -> scan -> fill took 35 + 30 + 52 us on the C3 frame); first[] is never cleared, only the
 // 8-byte heads are.
 // ------------------------------------------------------------------------------------------
+// How far an entry's depth key lies behind its face (see next_entry).  Too small loses the rest of a ray at a
+// non-matching interface; too large can only skip a stretch of grid THINNER than the slack that is followed by
+// another entry within the slack (both orders of two such keys are then possible) — a loss bounded by the
+// slack itself.  So it is generous: at least `floor_rel` of the face's extent (2^-18: 4e-6 of a cell; the
+// mixed-precision walk, whose exit depths carry fp32 noise of up to ~1e-5 of a cell, asks for 2^-12), and for
+// faces steep against the rays the rounding of their own plane: the plane is evaluated about the cell's vertex
+// 0, so c and gx * (x - x0) are of the size kappa * extent each and cancel, relative error eps * kappa on
+// gx: eps * kappa^2 * extent, kappa^2 = 1 + gx^2 + gy^2 (times 256: the cell across the interface may be
+// larger); plus the rounding of the absolute depth.  The steep term is capped at 2^-10 of the extent.
+__device__ __forceinline__ double entry_key_slack(double gx, double gy, double c, double extent, double floor_rel) {
+    if (floor_rel < 0.0) return 0.0;  // option "entry_key" 0 (testing): the face's own depth, as before round 3
+    const double kappa2 = fma(gx, gx, fma(gy, gy, 1.0));
+    const double steep = fmin(256.0 * DBL_EPSILON * kappa2, 0x1p-10);
+    return fmax(floor_rel, steep) * extent + 64.0 * DBL_EPSILON * fabs(c);
+}
+
 struct RasterArgs {
     const double* Xtab;
     const double* Ytab;
@@ -318,6 +345,7 @@ struct RasterArgs {
     FrameCounters* counters;
     unsigned* sticky;
     int want_upper;
+    double key_floor;  // entry_key_slack's floor_rel
 };
 
 // The work of one workgroup (four boundary faces); `block` is its index among the raster workgroups, so that
@@ -367,14 +395,17 @@ __device__ __forceinline__ void entry_raster_block(const GridView& g, const Rast
     const int i0 = (f == 3) ? 1 : 0;
     const int i1 = (f <= 1) ? 1 : 2;
     const int i2 = (f == 0) ? 2 : 3;
-    double ax, ay, bx, by, cx, cy;
+    double ax, ay, az, bx, by, bz, cx, cy, cz;
     {   // selects, not runtime indexing
         ax = i0 == 0 ? p[0][0] : p[1][0];
         ay = i0 == 0 ? p[0][1] : p[1][1];
+        az = i0 == 0 ? p[0][2] : p[1][2];
         bx = i1 == 1 ? p[1][0] : p[2][0];
         by = i1 == 1 ? p[1][1] : p[2][1];
+        bz = i1 == 1 ? p[1][2] : p[2][2];
         cx = i2 == 2 ? p[2][0] : p[3][0];
         cy = i2 == 2 ? p[2][1] : p[3][1];
+        cz = i2 == 2 ? p[2][2] : p[3][2];
     }
 
     const double xmin = fmin(ax, fmin(bx, cx)), xmax = fmax(ax, fmax(bx, cx));
@@ -400,7 +431,11 @@ __device__ __forceinline__ void entry_raster_block(const GridView& g, const Rast
     const unsigned n_box = bw * static_cast<unsigned>(lr1 - lr0 + 1);  // <= pixels of the image: fits 32 bits
 
     const double x0 = p[0][0], y0 = p[0][1];
-    const double pc = fp.c, pgx = fp.gx, pgy = fp.gy;
+    // depth key = the face's depth pushed entry_key_slack along the walk (down for upper faces, up for lower ones):
+    // once per face, folded into the plane's constant — nothing per pixel
+    const double extent = (xmax - xmin) + (ymax - ymin) + (fmax(az, fmax(bz, cz)) - fmin(az, fmin(bz, cz)));
+    const double slack = entry_key_slack(fp.gx, fp.gy, fp.c, extent, A.key_floor);
+    const double pc = fp.c + (want_upper ? -slack : slack), pgx = fp.gx, pgy = fp.gy;
 
     // The raster is bound by vector instructions (the box of a face holds 2.5x the pixels of the face), so
     // the per-pixel work is kept small: the three edge functions as planes about vertex a (two fused

@@ -136,6 +136,106 @@ def ball(n: int = 36, r: float = 0.45, centre=(1.0, 0.0, 0.0), jitter: float = 0
                     keep=lambda cen: np.linalg.norm(cen - c, axis=1) < r)
 
 
+def _kuhn_lattice(nx: int, ny: int, nz: int):
+    """Integer lattice points [(nx+1)(ny+1)(nz+1), 3] and the 6 Kuhn tets of every cube (ids into them)."""
+    gi, gj, gk = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1), np.arange(nz + 1), indexing="ij")
+    pts = np.stack([gi, gj, gk], axis=-1).reshape(-1, 3)
+    ci, cj, ck = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    base = np.stack([ci, cj, ck], axis=-1).reshape(-1, 3)
+    pid = lambda c: (c[:, 0] * (ny + 1) + c[:, 1]) * (nz + 1) + c[:, 2]  # noqa: E731
+    cells = []
+    for perm in _KUHN_PERMS:
+        v = [base.copy()]
+        for axis in perm:
+            nxt = v[-1].copy()
+            nxt[:, axis] += 1
+            v.append(nxt)
+        cells.append(np.stack([pid(c) for c in v], axis=1))
+    return pts, np.stack(cells, axis=1).reshape(-1, 4).astype(np.int32)
+
+
+def refined_interface(n: int = 3, nx_coarse: int = 2, nx_fine: int = 3, lo=(0.55, -0.4, -0.4), size: float = 0.8,
+                      jitter: float = 0.1, warp: float = 0.0, seed: int = 1234, weld: bool = True):
+    """A coarse Kuhn box (nx_coarse x n x n cubes of edge h = size / n) abutting a 2x-refined one
+    (nx_fine x 2n x 2n cubes of edge h / 2) across the plane x = lo.x + nx_coarse h: a grid that is conforming in
+    SPACE but not in connectivity.  Every coarse interface triangle is the union of four coplanar fine ones
+    (the fine interface nodes are the coarse nodes, the midpoints of the coarse edges and of the coarse
+    diagonals: hanging nodes), so no face of the interface has a partner with the same three points.  The
+    reference renders such grids like any other — it copies four points per cell and never looks at
+    connectivity (object3d_base.cpp:37-42), bins every face (plane.cpp:184-192) and sorts (line.cpp:138).
+
+    jitter: uniform displacement (units of the own cube edge) of the nodes strictly inside either box.
+    warp:   displacement (units of h, all three directions) of the coarse interface nodes off the rim, so that
+            the interface is a crumpled surface and not a plane; the hanging nodes follow (midpoints).
+    weld:   True -> coincident interface nodes share one id; False -> the two boxes keep their own points
+            (the library welds by coordinate, c5_weld_points).
+    Returns (xyz, cells, n_coarse_cells): cells [0, n_coarse_cells) are the coarse box.
+    """
+    rng = np.random.default_rng(seed)
+    h = size / n
+    lo = np.asarray(lo, dtype=np.float64)
+    # coarse box
+    pa, ca = _kuhn_lattice(nx_coarse, n, n)
+    xa = pa.astype(np.float64) * h
+    inner_a = (pa[:, 0] > 0) & (pa[:, 0] < nx_coarse) & (pa[:, 1] > 0) & (pa[:, 1] < n) & (pa[:, 2] > 0) & (pa[:, 2] < n)
+    xa[inner_a] += rng.uniform(-jitter * h, jitter * h, (int(inner_a.sum()), 3))
+    face_a = (pa[:, 0] == nx_coarse) & (pa[:, 1] > 0) & (pa[:, 1] < n) & (pa[:, 2] > 0) & (pa[:, 2] < n)
+    if warp > 0:
+        xa[face_a] += rng.uniform(-warp * h, warp * h, (int(face_a.sum()), 3))
+    xa += lo
+    # fine box
+    pb, cb = _kuhn_lattice(nx_fine, 2 * n, 2 * n)
+    hf = h / 2
+    xb = pb.astype(np.float64) * hf
+    xb[:, 0] += nx_coarse * h
+    inner_b = (pb[:, 0] > 0) & (pb[:, 0] < nx_fine) & (pb[:, 1] > 0) & (pb[:, 1] < 2 * n) & (pb[:, 2] > 0) & (pb[:, 2] < 2 * n)
+    xb[inner_b] += rng.uniform(-jitter * hf, jitter * hf, (int(inner_b.sum()), 3))
+    xb += lo
+    # its interface nodes: coarse nodes, edge midpoints, diagonal midpoints (the Kuhn diagonal of a y-z square runs
+    # from (j, k) to (j + 1, k + 1) on every x = const face)
+    coarse_id = lambda j, k: (nx_coarse * (n + 1) + j) * (n + 1) + k  # noqa: E731
+    on_face = np.nonzero(pb[:, 0] == 0)[0]
+    J, K = pb[on_face, 1], pb[on_face, 2]
+    j0, j1 = J // 2, (J + 1) // 2
+    k0, k1 = K // 2, (K + 1) // 2
+    xb[on_face] = 0.5 * (xa[coarse_id(j0, k0)] + xa[coarse_id(j1, k1)])  # (x + x) / 2 == x for the even-even nodes
+    xyz = np.vstack([xa, xb])
+    cells = np.vstack([ca, cb + len(xa)]).astype(np.int32)
+    if weld:
+        same = on_face[(J % 2 == 0) & (K % 2 == 0)]
+        remap = np.arange(len(xyz))
+        remap[len(xa) + same] = coarse_id(pb[same, 1] // 2, pb[same, 2] // 2)
+        cells = remap[cells]
+        used = np.unique(cells)
+        new_id = np.full(len(xyz), -1, dtype=np.int64)
+        new_id[used] = np.arange(used.size)
+        xyz = xyz[used]
+        cells = new_id[cells].astype(np.int32)
+    cells = orient_positive(xyz, cells)
+    validate(xyz, cells)
+    return xyz, cells, len(ca)
+
+
+def split_cell_at_edge_midpoint(xyz: np.ndarray, cells: np.ndarray, cell: int, edge=(0, 1)):
+    """Cut ONE cell in two through the midpoint of one of its edges and leave every other cell round that edge
+    as it is: a single hanging node.  The two faces of the cell that contain the edge become two faces each,
+    and the neighbours behind them keep their one face — conforming in space, not in connectivity.
+    Returns (xyz', cells') with the two halves in place of / behind the cut cell (ids of other cells unchanged)."""
+    xyz = np.asarray(xyz, dtype=np.float64)
+    cells = np.asarray(cells, dtype=np.int32).copy()
+    a, b = int(cells[cell][edge[0]]), int(cells[cell][edge[1]])
+    m = len(xyz)
+    xyz = np.vstack([xyz, 0.5 * (xyz[a] + xyz[b])])
+    first, second = cells[cell].copy(), cells[cell].copy()
+    first[edge[1]] = m   # (a, m, ., .)
+    second[edge[0]] = m  # (m, b, ., .)
+    cells[cell] = first
+    cells = np.vstack([cells, second[None, :]]).astype(np.int32)
+    cells = orient_positive(xyz, cells)
+    validate(xyz, cells)
+    return xyz, cells
+
+
 def per_cell_point_copies(xyz: np.ndarray, cells: np.ndarray):
     """The same grid as a soup: every cell gets four private points (what object3d_base::read_vtk_file
     keeps of a file, object3d_base.cpp:37-42, and what some writers emit).  Returns (xyz', cells')."""
@@ -155,6 +255,8 @@ def workload(name: str):
         xyz, cells = ball(36, 0.45)
     elif name == "c3":
         xyz, cells = kuhn_box(55, jitter=0.1)
+    elif name == "refined":  # coarse box against a 2x-refined one: hanging nodes all over the interface
+        xyz, cells, _ = refined_interface(3, 2, 3, jitter=0.1, warp=0.08)
     elif name.startswith("kuhn"):
         xyz, cells = kuhn_box(int(name[4:]), jitter=0.1)
     else:

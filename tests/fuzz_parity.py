@@ -2,7 +2,10 @@
 
     python tests/fuzz_parity.py [n_scenes] [seed0]
 
-Scenes: jittered Kuhn boxes with random cells removed (holes, non-convex, disconnected parts),
+Scenes: jittered Kuhn boxes with random cells removed (holes, non-convex, disconnected parts); every fifth scene
+a coarse box against a 2x-refined one (hanging nodes all over the interface, crumpled or planar, ids shared or
+not) with a few more cells cut at an edge midpoint, moved by an affine map that leaves the hanging nodes on their
+faces only to rounding;
 random anisotropic scaling / placement inside the domain, random views, scalars including zeros
 and values above the clamp, random image sizes, every kernel variant.  Reports every mismatch.
 """
@@ -25,8 +28,16 @@ def scene(seed):
     if dense:
         n = int(rng.integers(10, 19))
     keep_p = rng.uniform(0.55, 1.0)
-    xyz, cells = mg.kuhn_box(n, jitter=float(rng.uniform(0, 0.15)), seed=seed,
-                             keep=(lambda cen: rng.uniform(size=len(cen)) < keep_p) if keep_p < 0.98 else None)
+    if seed % 5 == 3:  # conforming in space, not in connectivity (SURVEY f-4)
+        xyz, cells, _ = mg.refined_interface(int(rng.integers(2, 6)), int(rng.integers(1, 4)), int(rng.integers(1, 5)),
+                                             lo=(0.0, 0.0, 0.0), size=1.0, jitter=float(rng.uniform(0, 0.15)),
+                                             warp=float(rng.choice([0.0, 0.05, 0.12])), seed=seed, weld=bool(rng.integers(0, 2)))
+        for _ in range(int(rng.integers(0, 4))):
+            e = rng.choice(4, 2, replace=False)
+            xyz, cells = mg.split_cell_at_edge_midpoint(xyz, cells, int(rng.integers(0, len(cells))), (int(e[0]), int(e[1])))
+    else:
+        xyz, cells = mg.kuhn_box(n, jitter=float(rng.uniform(0, 0.15)), seed=seed,
+                                 keep=(lambda cen: rng.uniform(size=len(cen)) < keep_p) if keep_p < 0.98 else None)
     # anisotropic scale + shift, staying inside x in [-0.2, 2.2], y in [-0.9, 0.9] after any rotation about (1,0,0)
     c = xyz.mean(axis=0)
     scale = rng.uniform(0.3, 0.9, 3)

@@ -10,6 +10,8 @@ oracle/ref_driver.cpp: the fp32 image [Y, X, 2], the segment count S
 (plane::count_all_intersections, plane.cpp:3-12) and the covered-pixel count.  The reference
 ships no fixtures of its own (no tests, data files git-ignored), so these are the golden
 vectors of the path.  Fixtures are data only.
+
+    python tests/golden/make_golden.py g7_ g8_     # only the fixtures whose name starts with one of these
 """
 import hashlib
 import os
@@ -24,6 +26,9 @@ from oracle.pyoracle import Oracle  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 VIEWS = ((0.0, 0.0), (0.1, 0.07), (0.5, 0.25))
+# grids with hanging nodes: the interface of g7 is (about) the plane x = const of the object, edge-on to the rays at
+# Y = 0: one generic view, two with the interface steep against the rays, one oblique from behind
+HANGING_VIEWS = ((0.1, 0.07), (0.3, 0.02), (0.0, 0.004), (0.37, -0.61))
 
 
 def special_alpha(n):
@@ -32,7 +37,17 @@ def special_alpha(n):
     return vals[np.arange(n) % len(vals)]
 
 
+def hanging_node_grid():
+    """The G2 grid with three of its cells cut in two through the midpoint of one edge each (a different edge of
+    the cell every time): three single hanging nodes; every other cell round those edges keeps its faces."""
+    xyz, cells = mg.kuhn_box(4, jitter=0.1)
+    for cell, edge in ((100, (0, 1)), (211, (1, 3)), (37, (0, 3))):
+        xyz, cells = mg.split_cell_at_edge_midpoint(xyz, cells, cell, edge)
+    return xyz, cells
+
+
 def main():
+    only = tuple(sys.argv[1:])
     ref = Oracle("reference")
     fixtures = []
     # G1: 8-tet cube, full 60x45 images + subsampled 600x450
@@ -50,11 +65,24 @@ def main():
     a, q = mg.scalars(len(cells))
     fixtures.append(("ball12_150x112", xyz, cells, a, q, 150, 112, 2.5, 1))
 
-    for name, xyz, cells, a, q, rx, ry, limit, stride in fixtures:
+    # G7 / G8 (round 3): conforming in space, not in connectivity — the reference never looks at connectivity
+    # (object3d_base.cpp:37-42 copies four points per cell, plane.cpp:184-192 bins every face, line.cpp:138 sorts)
+    xyz, cells, _ = mg.refined_interface(3, 2, 3, jitter=0.1, warp=0.08)
+    a, q = mg.scalars(len(cells), seed=3)
+    fixtures.append(("g7_refined_interface_160x120", xyz, cells, a, q, 160, 120, 2.5, 1, HANGING_VIEWS))
+    xyz, cells = hanging_node_grid()
+    a, q = mg.scalars(len(cells), seed=4)
+    fixtures.append(("g8_hanging_nodes_120x90", xyz, cells, a, q, 120, 90, 2.5, 1, HANGING_VIEWS))
+
+    for fx in fixtures:
+        name, xyz, cells, a, q, rx, ry, limit, stride = fx[:9]
+        views = fx[9] if len(fx) > 9 else VIEWS
+        if only and not name.startswith(only):
+            continue
         out = dict(xyz=xyz, cells=cells.astype(np.int32), alpha=a, q=q, res=np.array([rx, ry]),
                    bounds=np.array(mg.REFERENCE_BOUNDS), alpha_limit=np.array(limit),
-                   views=np.array(VIEWS), stride=np.array(stride))
-        for k, (ax, ay) in enumerate(VIEWS):
+                   views=np.array(views), stride=np.array(stride))
+        for k, (ax, ay) in enumerate(views):
             rots = mg.view_rotations(ax, ay)
             r = ref.render(xyz, cells, a, q, rots, rx, ry, mg.REFERENCE_BOUNDS, alpha_limit=limit)
             img = r["image"]
@@ -66,6 +94,8 @@ def main():
             print(name, (ax, ay), "S", r["segments"], "covered", r["covered"], "max", img.max(axis=(0, 1)))
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
+    if only:
+        return
     # G3: per-pixel segment lists of the reference's line::calculate_intersections (line.cpp:84-148) for 24 pixels of
     # the G2 fixture, view (0.1, 0.07): [(tetra id, delta z)] in the order std::sort leaves them
     xyz, cells, a, q = mg.workload("g2")
