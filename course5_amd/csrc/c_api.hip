@@ -162,6 +162,7 @@ struct c5_context {
     unsigned* host_sticky = nullptr;       // pinned copy, refreshed at the end of every frame
     std::vector<double> host_ytab;
     int row_costs = 0;
+    bool row_costs_collected = false;  // some frame since the rows were last laid out counted its segments per row
 
     // options
     double alpha_limit = 2.5;
@@ -262,6 +263,7 @@ int recompute_rows(c5_context* ctx) {
     for (int r = 0; r < im.res_y; ++r)
         if (c5::local_row_of(im, r) >= 0) ++n;
     im.n_local_rows = n;
+    ctx->row_costs_collected = false;
     return C5_OK;
 }
 
@@ -602,6 +604,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     if (ctx->row_costs && im.n_local_rows > 0) {
         wp.row_cost = fs.row_cost.as<uint32_t>();
         C5_HIP(ctx, hipMemsetAsync(fs.row_cost.ptr, 0, static_cast<size_t>(im.n_local_rows) * sizeof(uint32_t), s));
+        ctx->row_costs_collected = true;
     }
     if (ctx->pipeline) {
         C5_HIP(ctx, hipEventRecord(fs.setup_done, s));
@@ -738,6 +741,12 @@ int finish_frame(c5_context* ctx) {
     if (too_small || lost_rays) {
         int rc = drain(ctx);
         if (rc) return rc;
+        // Frames delivered to host memory that are still outstanding were all enqueued before this moment, i.e.
+        // rendered with the buffers that were too small: their waits must say so whatever their status snapshots
+        // read (a snapshot is copied on the copy stream and may run after the words are cleared here) — also when
+        // it is c5_get_stats / c5_get_row_costs / c5_synchronize, not c5_render_host_wait, that notices first.
+        if (too_small) ctx->hr_retry_left = ctx->hr_count;
+        if (ctx->copy_stream && ctx->hr_count) C5_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
         C5_HIP(ctx, hipMemset(ctx->sticky.ptr, 0, 2 * sizeof(unsigned)));
         ctx->host_sticky[0] = ctx->host_sticky[1] = 0;
     }
@@ -1167,7 +1176,9 @@ int c5_set_row_range(c5_context* ctx, int row_begin, int row_count) {
 
 int c5_get_row_costs(c5_context* ctx, uint32_t* costs, int n_rows) {
     if (!ctx || !costs) return fail(ctx, C5_ERR_INVALID, "null argument");
-    if (!ctx->row_costs) return fail(ctx, C5_ERR_STATE, "enable option \"row_costs\" before rendering");
+    // (the option may have been switched off again since: the costs of the last frame that counted them stay readable
+    // until the rows are laid out anew — a sweep probes one frame in many)
+    if (!ctx->row_costs_collected) return fail(ctx, C5_ERR_STATE, "enable option \"row_costs\" before rendering");
     if (n_rows != ctx->im.n_local_rows) return fail(ctx, C5_ERR_INVALID, "expected %d rows", ctx->im.n_local_rows);
     int rc = c5_synchronize(ctx);
     if (rc) return rc;
@@ -1425,7 +1436,8 @@ int c5_host_alloc(c5_context* ctx, size_t bytes, void** out_ptr) {
     int rc = bind_device(ctx);
     if (rc) return rc;
     *out_ptr = nullptr;
-    C5_HIP(ctx, hipHostMalloc(out_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    // portable: several contexts (one per GPU) copy their rows into the same frame (c5_render_frame_rows_async)
+    C5_HIP(ctx, hipHostMalloc(out_ptr, bytes ? bytes : 1, hipHostMallocPortable));
     return C5_OK;
 }
 

@@ -37,6 +37,8 @@ const option_spec kOptions[] = {
     {"devices", 0, true, "several GPUs of this node: 0-7 or 0,1,2 (one context per GPU, grid replicated)", nullptr},
     {"exchange", 0, true, "several GPUs, rows: host (each GPU copies its rows to the host image), rccl or p2p", "host"},
     {"split", 0, true, "several GPUs: rows, frames (frame k of a sweep on GPU k mod N) or auto", "auto"},
+    {"row_layout", 0, true, "several GPUs, rows: blocks (one contiguous cost-balanced block per GPU), tiles (cyclic) or auto", "auto"},
+    {"bench_files", 0, false, "--bench: write every timed frame to <destination>_NNNNN.vti like a sweep (end to end with files)", nullptr},
     {"bench", 0, true, "render this many sweep frames without writing files and print one JSON line", nullptr},
     {"bench_warmup", 0, true, "untimed frames before --bench", "20"},
     {"auto_bounds", 0, false, "image domain = bounding box of the transformed objects instead of the fixed domain", nullptr},
@@ -130,6 +132,8 @@ bool program_options(int argc, char** argv, std::ostream& out) {
         else if (n == "devices") cfg.devices = v;
         else if (n == "exchange") cfg.exchange = v;
         else if (n == "split") cfg.split = v;
+        else if (n == "row_layout") cfg.row_layout = v;
+        else if (n == "bench_files") cfg.bench_files = true;
         else if (n == "bench") cfg.bench = static_cast<std::size_t>(std::max(0ll, to_integer(n, v)));
         else if (n == "bench_warmup") cfg.bench_warmup = static_cast<std::size_t>(std::max(0ll, to_integer(n, v)));
         else if (n == "auto_bounds") cfg.auto_bounds = true;
@@ -197,11 +201,13 @@ bool program_options(int argc, char** argv, std::ostream& out) {
         return false;
     }
     if (!cfg.selftest_vti.empty() || cfg.rccl_selftest) return true;
-    if (cfg.bench > 0 && have_file && !have_dest) have_dest = true;  // a benchmark writes no file
+    if (cfg.bench > 0 && !cfg.bench_files && have_file && !have_dest) have_dest = true;  // a benchmark writes no file
     if (cfg.exchange != "host" && cfg.exchange != "rccl" && cfg.exchange != "p2p")
         throw std::runtime_error("the argument ('" + cfg.exchange + "') for option '--exchange' is invalid");
     if (cfg.split != "auto" && cfg.split != "rows" && cfg.split != "frames")
         throw std::runtime_error("the argument ('" + cfg.split + "') for option '--split' is invalid");
+    if (cfg.row_layout != "auto" && cfg.row_layout != "blocks" && cfg.row_layout != "tiles")
+        throw std::runtime_error("the argument ('" + cfg.row_layout + "') for option '--row_layout' is invalid");
     if (!(have_file && have_dest)) {  // main.cpp:43-51
         out << "Error! Source filename and destination filename must be specified" << std::endl;
         print_usage(out);

@@ -26,6 +26,9 @@ struct render_config {
     std::string exchange = "host";  // how rows rendered by several GPUs come together: host, rccl or p2p (plane.hpp)
     std::string split = "auto";   // several GPUs: rows (every frame split by rows) or frames (frame k -> GPU k mod N);
                                   // auto = frames for a sweep, rows for a single frame
+    std::string row_layout = "auto";  // rows split: blocks (one contiguous cost-balanced block per GPU), tiles (cyclic 16-row
+                                      // tiles) or auto = blocks for a sweep, tiles for a single frame
+    bool bench_files = false;     // --bench writes every timed frame like a sweep does (end-to-end figure with files)
     bool auto_bounds = false;     // image domain = bounding box of the transformed objects (plane.cpp:278-288) instead of main.cpp:83's
     std::size_t bench = 0;        // > 0: render this many frames of the sweep without writing files, print one JSON line
     std::size_t bench_warmup = 20;

@@ -5,11 +5,15 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <deque>
+#include <exception>
 #include <memory>
 #include <iostream>
 #include <limits>
+#include <mutex>
 #include <stdexcept>
 #include <thread>
 
@@ -44,6 +48,150 @@ void write_frame(const object2d& img, const std::string& name) {
     img.export_to_vti(name);
     if (app::instance().config.png) img.export_to_png(png_name(name));
 }
+
+// A bounded hand-over between threads: push blocks while `capacity` items wait, pop blocks until an item arrives or
+// the queue is closed.
+template <class T>
+class channel {
+public:
+    explicit channel(std::size_t capacity) : _capacity(capacity) {}
+    void push(T item) {
+        std::unique_lock<std::mutex> hold(_lock);
+        _room.wait(hold, [&] { return _items.size() < _capacity || _closed; });
+        if (_closed) return;
+        _items.push_back(std::move(item));
+        _ready.notify_one();
+    }
+    bool pop(T& out) {
+        std::unique_lock<std::mutex> hold(_lock);
+        _ready.wait(hold, [&] { return !_items.empty() || _closed; });
+        if (_items.empty()) return false;
+        out = std::move(_items.front());
+        _items.pop_front();
+        _room.notify_one();
+        return true;
+    }
+    void close() {
+        std::lock_guard<std::mutex> hold(_lock);
+        _closed = true;
+        _ready.notify_all();
+        _room.notify_all();
+    }
+
+private:
+    std::size_t _capacity;
+    std::mutex _lock;
+    std::condition_variable _ready, _room;
+    std::deque<T> _items;
+    bool _closed = false;
+};
+
+// The files of a sweep are written by a thread of their own (object2d::export_to_vti widens, deflates and encodes
+// on the OpenMP team it starts), so that a sweep with output lasts max(render, write) per frame and not their sum:
+// the reference's workload is exactly this (utility/rotate_traces.py:16-21 renders 1 500 frames to files).  Frames
+// arrive as pinned images of the planes' pools and go back to them when written; the queue bounds how many wait.
+class frame_writer {
+public:
+    explicit frame_writer(int omp_threads) : _queue(4), _thread([this, omp_threads] { run(omp_threads); }) {}
+    ~frame_writer() {
+        _queue.close();
+        if (_thread.joinable()) _thread.join();
+    }
+    void write(object2d img, std::string name) { _queue.push({std::move(img), std::move(name)}); }
+    // all files written; throws what the writer thread ran into
+    void finish() {
+        _queue.close();
+        if (_thread.joinable()) _thread.join();
+        if (_error) std::rethrow_exception(_error);
+    }
+    std::size_t written() const { return _written; }
+
+private:
+    struct item {
+        object2d img;
+        std::string name;
+    };
+    void run(int omp_threads) {
+        omp_set_num_threads(omp_threads);
+        item it;
+        while (_queue.pop(it)) {
+            try {
+                if (!_error) write_frame(it.img, it.name);
+                ++_written;
+            } catch (...) {
+                if (!_error) _error = std::current_exception();
+            }
+            it = item{};  // the image goes back to its pool now, not when the next one arrives
+        }
+    }
+    channel<item> _queue;
+    std::exception_ptr _error;
+    std::size_t _written = 0;
+    std::thread _thread;
+};
+
+// One thread per plane (per GPU when a sweep is split by frames): it issues the frames dealt to it ahead
+// (find_intersections returns at once) and retires them in order, so that N GPUs are driven by N host threads — ten
+// HIP calls per 0.7 ms frame and GPU are the whole budget of one.
+struct frame_job {
+    std::size_t k = 0;
+    plane::views_t views;
+    bool write = false;
+};
+class plane_driver {
+public:
+    plane_driver(plane& p, std::size_t depth, frame_writer* writer, const render_config& config, bool stats_between)
+        : _plane(p), _depth(depth), _writer(writer), _config(config), _stats_between(stats_between), _jobs(2 * depth + 2),
+          _thread([this] { run(); }) {}
+    ~plane_driver() {
+        _jobs.close();
+        if (_thread.joinable()) _thread.join();
+    }
+    void issue(frame_job job) { _jobs.push(std::move(job)); }
+    void finish() {
+        _jobs.close();
+        if (_thread.joinable()) _thread.join();
+        if (_error) std::rethrow_exception(_error);
+    }
+
+private:
+    void retire() {
+        const frame_job job = std::move(_flight.front());
+        _flight.pop_front();
+        // test hook (C5_TEST_STATS_BETWEEN): the reference's count_all_intersections() may be called between
+        // find_intersections() and trace_rays(); a C5_RETRY it runs into must not be lost
+        if (_stats_between) (void)_plane.count_all_intersections();
+        object2d img = _plane.trace_rays(tetra_value::alpha, tetra_value::Q);
+        // (--bench --bench_files: numbered names like a sweep's, whatever --frames says)
+        if (job.write && _writer)
+            _writer->write(std::move(img), frame_name(_config.destination, job.k, _config.bench > 0 ? std::max<std::size_t>(_config.frames, 2) : _config.frames));
+    }
+    void run() {
+        try {
+            frame_job job;
+            while (_jobs.pop(job)) {
+                while (_flight.size() >= _depth) retire();
+                _plane.set_views(job.views);
+                _plane.find_intersections();
+                _flight.push_back(std::move(job));
+            }
+            while (!_flight.empty()) retire();
+        } catch (...) {
+            _error = std::current_exception();
+            frame_job drop;
+            while (_jobs.pop(drop)) {}  // keep the dealing thread from blocking on a full queue
+        }
+    }
+    plane& _plane;
+    std::size_t _depth;
+    frame_writer* _writer;
+    const render_config& _config;
+    bool _stats_between;
+    channel<frame_job> _jobs;
+    std::deque<frame_job> _flight;
+    std::exception_ptr _error;
+    std::thread _thread;
+};
 }  // namespace
 
 int main(int argc, char** argv) try {
@@ -162,6 +310,11 @@ int main(int argc, char** argv) try {
                                    : config.exchange == "p2p" ? exchange_mode::p2p : exchange_mode::host;
     const bool is_sweep = config.frames > 1 || config.bench > 0;
     const bool by_frames = devices.size() > 1 && (config.split == "frames" || (config.split == "auto" && is_sweep));
+    // rows of one frame shared by several GPUs: contiguous cost-balanced blocks need an earlier frame to measure, so
+    // a single frame is dealt in cyclic tiles (balanced by construction) unless told otherwise
+    const row_layout layout = config.row_layout == "blocks"  ? row_layout::blocks
+                              : config.row_layout == "tiles" ? row_layout::tiles
+                                                             : (is_sweep ? row_layout::blocks : row_layout::tiles);
 
     t1 = timestamp();
     std::vector<std::unique_ptr<plane>> planes;
@@ -182,7 +335,7 @@ int main(int argc, char** argv) try {
         for (const std::string& e : errors)
             if (!e.empty()) throw std::runtime_error(e);
     } else {
-        planes.push_back(std::make_unique<plane>(config.resolution_x, config.resolution_y, objects, domain, devices, exchange));
+        planes.push_back(std::make_unique<plane>(config.resolution_x, config.resolution_y, objects, domain, devices, exchange, layout));
     }
     plane& base_plane = *planes[0];
     base_plane.find_intersections();
@@ -199,76 +352,86 @@ int main(int argc, char** argv) try {
                   << " solid pixels" << std::endl;
     }
 
-    // sweep: the grid, its adjacency and the solids stay on the GPU(s); only rotation lists change.  Frames are
-    // issued ahead (find_intersections returns at once) and retired in order: while frame k is being written,
+    // sweep: the grid, its adjacency and the solids stay on the GPU(s); only rotation lists change.  This thread
+    // works out the angles of frame k and deals it to the driver of plane k mod N; every driver issues its frames
+    // ahead and retires them in order; retired frames go to the writer thread.  While frame k is being written,
     // frames k + 1 ... are rendered and copied to pinned host images.
-    struct pending_frame {
-        std::size_t k;
-        plane* p;
-    };
-    std::deque<pending_frame> in_flight;
     const std::size_t per_plane = (by_frames || exchange == exchange_mode::host) ? 2 : 1;
-    const std::size_t max_in_flight = per_plane * planes.size();
     double* const swept = config.sweep == "X"   ? &view.angle_around_x
                           : config.sweep == "D" ? &view.donor_angle
                           : config.sweep == "I" ? &view.system_initial_angle_around_y
                                                 : &view.angle_around_y;
-    auto issue = [&](std::size_t k, bool advance) {
-        if (advance) *swept += config.sweep_step;
-        apply_view(objects[0], roche_lobe ? &objects[1] : nullptr);
-        plane* p = planes[k % planes.size()].get();
-        p->update_views(objects);
-        p->find_intersections();
-        in_flight.push_back({k, p});
-    };
-    auto retire = [&](bool write) {
-        const pending_frame f = in_flight.front();
-        in_flight.pop_front();
-        object2d img = f.p->trace_rays(tetra_value::alpha, tetra_value::Q);
-        if (write) write_frame(img, frame_name(config.destination, f.k, config.frames));
+    const bool stats_between = std::getenv("C5_TEST_STATS_BETWEEN") != nullptr;
+    auto run_frames = [&](std::size_t first, std::size_t count, bool advance, bool write) {
+        std::unique_ptr<frame_writer> writer;
+        if (write) writer = std::make_unique<frame_writer>(static_cast<int>(std::max<std::size_t>(1, config.threads)));
+        {
+            std::vector<std::unique_ptr<plane_driver>> drivers;
+            for (auto& p : planes) drivers.push_back(std::make_unique<plane_driver>(*p, per_plane, writer.get(), config, stats_between));
+            for (std::size_t k = first; k < first + count; ++k) {
+                if (advance) *swept += config.sweep_step;
+                apply_view(objects[0], roche_lobe ? &objects[1] : nullptr);
+                frame_job job;
+                job.k = k;
+                job.views = planes[k % planes.size()]->views_of(objects);
+                job.write = write;
+                drivers[k % planes.size()]->issue(std::move(job));
+            }
+            std::exception_ptr first_error;
+            for (auto& d : drivers) {
+                try {
+                    d->finish();
+                } catch (...) {
+                    if (!first_error) first_error = std::current_exception();
+                }
+            }
+            if (first_error) std::rethrow_exception(first_error);
+        }
+        if (writer) writer->finish();
     };
     if (config.bench == 0) {
-        for (std::size_t k = 1; k < config.frames; ++k) {
-            while (in_flight.size() >= max_in_flight) retire(true);
-            issue(k, true);
-        }
-        while (!in_flight.empty()) retire(true);
+        if (config.frames > 1) run_frames(1, config.frames - 1, true, true);
         if (config.frames > 1) {
             const auto t3 = timestamp();
             std::cout << config.frames - 1 << " further frames in " << ms_between(t2, t3) << " ms. " << std::endl;
         }
         if (config.print_stats) {
-            std::size_t again = 0;
-            for (const auto& p : planes) again += p->retries();
+            std::size_t again = 0, moved = 0;
+            for (const auto& p : planes) again += p->retries(), moved += p->rebalances();
             std::cout << "Frames rendered again after an internal buffer grew: " << again << std::endl;
+            if (devices.size() > 1 && !by_frames) {
+                std::cout << "Row blocks laid out anew: " << moved << "; rows per GPU:";
+                for (const auto& b : base_plane.row_blocks()) std::cout << " " << b.second;
+                std::cout << std::endl;
+            }
         }
     } else {
-        // --bench: frames rendered and delivered to host memory, no files.  One JSON line.
-        for (std::size_t k = 0; k < config.bench_warmup; ++k) {
-            while (in_flight.size() >= max_in_flight) retire(false);
-            issue(k, false);
-        }
-        while (!in_flight.empty()) retire(false);
+        // --bench: frames rendered and delivered to host memory, no files — or, with --bench_files, written like a
+        // sweep's (end to end: render + copy + deflate + file).  One JSON line.
+        run_frames(0, config.bench_warmup, false, false);
         std::size_t retries0 = 0;
         for (const auto& p : planes) retries0 += p->retries();
         const auto b0 = std::chrono::steady_clock::now();
-        for (std::size_t k = 0; k < config.bench; ++k) {
-            while (in_flight.size() >= max_in_flight) retire(false);
-            issue(k, config.sweep_step != 0.0);
-        }
-        while (!in_flight.empty()) retire(false);
+        run_frames(0, config.bench, config.sweep_step != 0.0, config.bench_files);
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - b0).count();
-        std::size_t retries1 = 0;
-        for (const auto& p : planes) retries1 += p->retries();
+        std::size_t retries1 = 0, moved = 0;
+        for (const auto& p : planes) retries1 += p->retries(), moved += p->rebalances();
         const double rays = static_cast<double>(config.resolution_x) * static_cast<double>(config.resolution_y);
-        std::printf("{\"course_bench\": {\"frames\": %zu, \"warmup\": %zu, \"ms_per_frame\": %.4f, \"mrays_per_s\": %.1f, "
-                    "\"res_x\": %zu, \"res_y\": %zu, \"n_devices\": %zu, \"split\": \"%s\", \"exchange\": \"%s\", "
+        std::string rows = "[";
+        for (const auto& b : base_plane.row_blocks()) rows += (rows.size() > 1 ? ", " : "") + std::to_string(b.second);
+        rows += "]";
+        std::printf("{\"course_bench\": {\"frames\": %zu, \"warmup\": %zu, \"ms_per_frame\": %.4f, \"mrays_per_s\": %.1f, \"frames_per_s\": %.2f, "
+                    "\"res_x\": %zu, \"res_y\": %zu, \"n_devices\": %zu, \"split\": \"%s\", \"exchange\": \"%s\", \"row_layout\": \"%s\", "
+                    "\"rows_per_device\": %s, \"rebalances\": %zu, "
                     "\"sweep\": \"%s\", \"sweep_step\": %g, \"solids\": %s, \"retries\": %zu, "
-                    "\"delivered_to\": \"pinned host memory\"}}\n",
+                    "\"delivered_to\": \"%s\"}}\n",
                     config.bench, config.bench_warmup, secs * 1e3 / static_cast<double>(config.bench),
-                    rays * static_cast<double>(config.bench) / secs / 1e6, config.resolution_x, config.resolution_y, devices.size(),
+                    rays * static_cast<double>(config.bench) / secs / 1e6, static_cast<double>(config.bench) / secs,
+                    config.resolution_x, config.resolution_y, devices.size(),
                     devices.size() == 1 ? "none" : (by_frames ? "frames" : "rows"), by_frames ? "none" : config.exchange.c_str(),
-                    config.sweep.c_str(), config.sweep_step, config.no_solids ? "false" : "true", retries1 - retries0);
+                    (devices.size() == 1 || by_frames) ? "none" : (layout == row_layout::blocks ? "blocks" : "tiles"), rows.c_str(), moved,
+                    config.sweep.c_str(), config.sweep_step, config.no_solids ? "false" : "true", retries1 - retries0,
+                    config.bench_files ? (config.raw_vti ? "raw .vti files" : "zlib .vti files") : "pinned host memory");
         std::fflush(stdout);
     }
     std::cout << "Result exported. Calculations completed." << std::endl;

@@ -16,6 +16,10 @@
 
 namespace {
 constexpr int kTileRows = 16;  // one workgroup row of 8x8 wavefront tiles
+constexpr std::size_t kProbeEvery = 64;   // blocks layout: every so many frames the walk counts segments per row
+constexpr double kRowBaseCost = 6.0;      // per pixel, in segments: what a pixel costs whether or not it meets the grid
+                                          // (bench.py --row-base-cost, scripts/sim_scaling.py: the same figure)
+constexpr double kRebalanceGain = 1.08;   // blocks move when the dearest block is this much above what new blocks promise
 
 void hip_check(hipError_t e, const char* what) {
     if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
@@ -72,18 +76,23 @@ image_pool::~image_pool() {
 
 std::shared_ptr<float> image_pool::take() {
     float* p = nullptr;
-    if (!_free.empty()) {
-        p = _free.back();
-        _free.pop_back();
-    } else {
-        hip_check(hipHostMalloc(reinterpret_cast<void**>(&p), _bytes ? _bytes : 1, hipHostMallocDefault), "hipHostMalloc of an image");
+    {
+        std::lock_guard<std::mutex> hold(_lock);
+        if (!_free.empty()) {
+            p = _free.back();
+            _free.pop_back();
+        }
     }
+    if (!p)  // portable: visible as pinned memory to every device's context, not only the one current here
+        hip_check(hipHostMalloc(reinterpret_cast<void**>(&p), _bytes ? _bytes : 1, hipHostMallocPortable), "hipHostMalloc of an image");
     std::weak_ptr<image_pool> home = shared_from_this();
     return std::shared_ptr<float>(p, [home](float* q) {
-        if (auto pool = home.lock())
+        if (auto pool = home.lock()) {
+            std::lock_guard<std::mutex> hold(pool->_lock);
             pool->_free.push_back(q);
-        else
+        } else {
             (void)hipHostFree(q);
+        }
     });
 }
 
@@ -153,6 +162,28 @@ struct multi_gpu {
     }
 };
 
+std::vector<std::pair<int, int>> balanced_row_blocks(const std::vector<uint32_t>& row_cost, int world, double base_cost_per_row) {
+    const int res_y = static_cast<int>(row_cost.size());
+    if (world < 1 || res_y < world) throw std::runtime_error("more devices than image rows");
+    std::vector<double> cum(static_cast<std::size_t>(res_y) + 1, 0.0);
+    for (int r = 0; r < res_y; ++r) cum[static_cast<std::size_t>(r) + 1] = cum[static_cast<std::size_t>(r)] + static_cast<double>(row_cost[static_cast<std::size_t>(r)]) + base_cost_per_row;
+    const double total = cum.back();
+    std::vector<int> edge{0};
+    for (int r = 1; r < world; ++r) {
+        const double target = total * r / world;
+        int e = static_cast<int>(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());  // first cum[e] >= target
+        // nearer of the two candidate cuts
+        if (e > 0 && std::fabs(cum[static_cast<std::size_t>(e) - 1] - target) <= std::fabs(cum[static_cast<std::size_t>(std::min(e, res_y))] - target)) --e;
+        e = std::max(e, edge.back() + 1);
+        e = std::min(e, res_y - (world - r));
+        edge.push_back(e);
+    }
+    edge.push_back(res_y);
+    std::vector<std::pair<int, int>> blocks;
+    for (int r = 0; r < world; ++r) blocks.emplace_back(edge[static_cast<std::size_t>(r)], edge[static_cast<std::size_t>(r) + 1] - edge[static_cast<std::size_t>(r)]);
+    return blocks;
+}
+
 std::string rccl_selftest(int device) {
     rccl_api& nccl = rccl_api::get();
     if (!nccl.ok) throw std::runtime_error(nccl.error);
@@ -196,13 +227,46 @@ std::string rccl_selftest(int device) {
             wrong += back[tile_floats * static_cast<std::size_t>(gt) + k] != want;
         }
     }
+    // blocks layout: the frame is three blocks of rows; block 0 is "rendered in place" by the root, blocks 1 and 2 are
+    // peers' strips, each landed by ONE ncclSend / ncclRecv pair (one message per GPU and frame), both
+    // pairs in one group — the root receives from all its peers at once
+    const std::size_t rows_total = 2 * static_cast<std::size_t>(n_tiles) * kTileRows;
+    const std::size_t b_begin[3] = {0, 37, 37 + 64}, b_rows[3] = {37, 64, rows_total - 37 - 64};
+    std::size_t wrong_blocks = 0;
+    {
+        hip_check(hipMemset(frame, 0, frame_floats * sizeof(float)), "hipMemset");
+        float* peer[3] = {nullptr, nullptr, nullptr};
+        std::vector<std::vector<float>> src(3);
+        for (int b = 1; b < 3; ++b) {
+            src[b].resize(b_rows[b] * row_floats);
+            for (std::size_t k = 0; k < src[b].size(); ++k) src[b][k] = static_cast<float>((k * 7 + static_cast<std::size_t>(b)) % 99991) + 0.5f;
+            hip_check(hipMalloc(reinterpret_cast<void**>(&peer[b]), src[b].size() * sizeof(float)), "hipMalloc");
+            hip_check(hipMemcpy(peer[b], src[b].data(), src[b].size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy");
+        }
+        rc = nccl.GroupStart();
+        for (int b = 1; b < 3 && rc == ncclSuccess; ++b) {
+            rc = nccl.Send(peer[b], b_rows[b] * row_floats, ncclFloat, 0, comm, s);
+            if (rc == ncclSuccess) rc = nccl.Recv(frame + b_begin[b] * row_floats, b_rows[b] * row_floats, ncclFloat, 0, comm, s);
+        }
+        const ncclResult_t end2 = nccl.GroupEnd();
+        if (rc != ncclSuccess || end2 != ncclSuccess)
+            throw std::runtime_error(std::string("RCCL self-test (blocks): ") + nccl.GetErrorString(rc != ncclSuccess ? rc : end2));
+        hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+        hip_check(hipMemcpy(back.data(), frame, frame_floats * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy");
+        for (std::size_t k = 0; k < b_rows[0] * row_floats; ++k) wrong_blocks += back[k] != 0.0f;
+        for (int b = 1; b < 3; ++b)
+            for (std::size_t k = 0; k < src[b].size(); ++k) wrong_blocks += back[b_begin[b] * row_floats + k] != src[b][k];
+        for (int b = 1; b < 3; ++b) (void)hipFree(peer[b]);
+    }
     (void)nccl.CommDestroy(comm);
     (void)hipStreamDestroy(s);
     (void)hipFree(strip);
     (void)hipFree(frame);
     if (wrong) throw std::runtime_error("RCCL self-test: " + std::to_string(wrong) + " floats in the wrong place");
+    if (wrong_blocks) throw std::runtime_error("RCCL self-test (blocks): " + std::to_string(wrong_blocks) + " floats in the wrong place");
     return "RCCL self-test ok: librccl loaded, communicator over device " + std::to_string(device) + ", " + std::to_string(n_tiles) +
-           " grouped ncclSend/ncclRecv pairs landed " + std::to_string(strip_floats) + " floats at their tile offsets";
+           " grouped ncclSend/ncclRecv pairs landed " + std::to_string(strip_floats) + " floats at their tile offsets; 2 pairs (one per peer) landed " +
+           std::to_string((b_rows[1] + b_rows[2]) * row_floats) + " floats as whole row blocks";
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -262,8 +326,8 @@ void plane::check(int rc, const char* what, std::size_t dev) {
 }
 
 plane::plane(std::size_t res_x, std::size_t res_y, std::vector<object3d_base> objects3d,
-             std::vector<double> global_boundaries, std::vector<int> devices, exchange_mode exchange)
-    : _devices(std::move(devices)), _exchange(exchange) {
+             std::vector<double> global_boundaries, std::vector<int> devices, exchange_mode exchange, row_layout layout)
+    : _devices(std::move(devices)), _exchange(exchange), _layout(layout) {
     if (!global_boundaries.empty() && global_boundaries.size() != 4)
         throw std::runtime_error("plane initializer. wrong manual boundaries");  // plane.cpp:262-264
     if (objects3d.empty())
@@ -276,6 +340,8 @@ plane::plane(std::size_t res_x, std::size_t res_y, std::vector<object3d_base> ob
     _x = res_x;
     _y = res_y;
     const int world = static_cast<int>(_devices.size());
+    if (world > 1 && res_y < static_cast<std::size_t>(world)) throw std::runtime_error("plane initializer. more GPUs than image rows");
+    _retry_seen.assign(_devices.size(), 0);
 
     // volume grids are merged into one indexed grid (the reference concatenates tetra vectors,
     // plane.cpp:290-293); solids keep one slot each, in order
@@ -304,6 +370,15 @@ plane::plane(std::size_t res_x, std::size_t res_y, std::vector<object3d_base> ob
     }
     _views.solids.resize(static_cast<std::size_t>(next_slot));
 
+    // blocks layout: equal blocks to start with; the first frame counts its segments per row, and the blocks are
+    // balanced by that before the second (read_row_costs / apply_blocks)
+    if (world > 1 && _layout == row_layout::blocks)
+        for (int r = 0; r < world; ++r) {
+            const int lo = static_cast<int>(res_y * static_cast<std::size_t>(r) / static_cast<std::size_t>(world));
+            const int hi = static_cast<int>(res_y * static_cast<std::size_t>(r + 1) / static_cast<std::size_t>(world));
+            _blocks.emplace_back(lo, hi - lo);
+        }
+
     // one context per device, the grid replicated (52 MB at 1M cells; pixels are independent,
     // plane.cpp:161-169, so nothing but the image is ever exchanged)
     for (int r = 0; r < world; ++r) {
@@ -319,7 +394,8 @@ plane::plane(std::size_t res_x, std::size_t res_y, std::vector<object3d_base> ob
             check(c5_upload_grid(ctx, pts.data(), static_cast<int64_t>(pts.size() / 3), cells.data(),
                                  static_cast<int64_t>(cells.size() / 4), a.data(), q.data()),
                   "c5_upload_grid", k);
-        if (world > 1) check(c5_set_row_tiles(ctx, kTileRows, r, world), "c5_set_row_tiles", k);
+        if (world > 1 && _layout == row_layout::tiles) check(c5_set_row_tiles(ctx, kTileRows, r, world), "c5_set_row_tiles", k);
+        if (world > 1 && _layout == row_layout::blocks) check(c5_set_row_range(ctx, _blocks[k].first, _blocks[k].second), "c5_set_row_range", k);
         check(c5_set_image(ctx, static_cast<int>(res_x), static_cast<int>(res_y), global_boundaries.data()), "c5_set_image", k);
         check(c5_set_alpha_limit(ctx, app::instance().config.limit_alpha_value), "c5_set_alpha_limit", k);  // line.cpp:204
         if (app::instance().config.reference_algorithm) check(c5_set_option(ctx, "algorithm", 1.0), "c5_set_option", k);
@@ -345,8 +421,12 @@ plane::plane(std::size_t res_x, std::size_t res_y, std::vector<object3d_base> ob
             hip_check(hipEventCreateWithFlags(&m.done[r], hipEventDisableTiming), "hipEventCreate");
             check(c5_set_stream(_ctx[r], m.stream[r]), "c5_set_stream", r);
             check(c5_local_rows(_ctx[r], &m.n_rows[r]), "c5_local_rows", r);
-            const std::size_t bytes = static_cast<std::size_t>(m.n_rows[r]) * res_x * 2 * sizeof(float);
-            hip_check(hipMalloc(reinterpret_cast<void**>(&m.strip[r]), bytes ? bytes : 8), "hipMalloc of a strip");
+            // blocks move between frames: a strip has room for any block (the whole image: 35 MB at 2400x1800)
+            const std::size_t rows = _layout == row_layout::blocks ? res_y : static_cast<std::size_t>(m.n_rows[r]);
+            const std::size_t bytes = rows * res_x * 2 * sizeof(float);
+            // (the root's block is rendered straight into the root image: it needs no strip in the blocks layout)
+            if (!(r == 0 && world > 1 && _layout == row_layout::blocks))
+                hip_check(hipMalloc(reinterpret_cast<void**>(&m.strip[r]), bytes ? bytes : 8), "hipMalloc of a strip");
             if (r > 0 && _devices[r] != _devices[0]) {
                 const hipError_t e = hipDeviceEnablePeerAccess(_devices[0], 0);
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) hip_check(e, "hipDeviceEnablePeerAccess");
@@ -398,56 +478,138 @@ void plane::send_views(const views_t& v) {
     }
 }
 
-void plane::update_views(std::vector<object3d_base>& objects3d) {
+plane::views_t plane::views_of(std::vector<object3d_base>& objects3d) const {
+    views_t v;
+    v.solids.resize(_views.solids.size());
     bool grid_view_set = false;
     for (std::size_t k = 0; k < objects3d.size() && k < _slot_of_object.size(); ++k) {
         const object3d_data& d = *objects3d[k].get_pointer();
         if (_slot_of_object[k] < 0) {
-            if (!grid_view_set) _views.grid = d.rotations;
+            if (!grid_view_set) v.grid = d.rotations;
             grid_view_set = true;
         } else {
-            _views.solids[static_cast<std::size_t>(_slot_of_object[k])] = d.rotations;
+            v.solids[static_cast<std::size_t>(_slot_of_object[k])] = d.rotations;
         }
     }
+    return v;
+}
+
+void plane::set_views(const views_t& v) {
+    _views = v;
     send_views(_views);
 }
 
 void plane::start(frame_t& f) {
+    const bool blocks = _ctx.size() > 1 && _layout == row_layout::blocks;
     for (std::size_t r = 0; r < _ctx.size(); ++r) {
-        if (_exchange == exchange_mode::host)
+        if (blocks) check(c5_set_option(_ctx[r], "row_costs", f.probe ? 1.0 : 0.0), "c5_set_option", r);
+        if (_exchange == exchange_mode::host) {
             check(c5_render_frame_rows_async(_ctx[r], f.image.get()), "find_intersections", r);
-        else
-            check(c5_render_device(_ctx[r], _mg->strip[r]), "find_intersections", r);
+        } else {
+            // blocks: the root's own block is rendered in place, at its final offset of the root image
+            float* const target = (blocks && r == 0) ? _mg->root_frame + static_cast<std::size_t>(_blocks[0].first) * _x * 2 : _mg->strip[r];
+            check(c5_render_device(_ctx[r], target), "find_intersections", r);
+        }
     }
+}
+
+bool plane::retry_seen() {
+    bool any = false;
+    for (char& c : _retry_seen) {
+        any = any || c != 0;
+        c = 0;
+    }
+    return any;
 }
 
 void plane::find_intersections() {
     const std::size_t limit = _exchange == exchange_mode::host ? C5_HOST_RING : 1;
     if (_flight.size() >= limit)
         throw std::runtime_error("find_intersections: " + std::to_string(limit) + " frame(s) already in flight, call trace_rays first");
+    if (_rebalance_due) {
+        // The rows are laid out anew between frames: whatever is in flight finishes first and is parked, in order,
+        // for the trace_rays calls to come.  (A probe frame among them is not read: its layout is about to go.)
+        while (!_flight.empty()) {
+            complete_front();
+            _parked.push_back(std::move(_flight.front()));
+            _flight.pop_front();
+        }
+        apply_blocks(_wanted_blocks);
+        _rebalance_due = false;
+    }
     frame_t f;
     f.image = _pool->take();
     f.views = _views;
+    f.probe = _ctx.size() > 1 && _layout == row_layout::blocks && (_issued % kProbeEvery == 0);
+    ++_issued;
     start(f);
     _flight.push_back(std::move(f));
 }
 
-// rccl / p2p: every strip is known complete (status checked) before anything is exchanged; every tile lands
+// blocks layout, after a probe frame completed: every device hands over the segments of its rows; together they are
+// the cost of every row of the image.  If balanced blocks would make the dearest block at least kRebalanceGain
+// cheaper than it is now, the next find_intersections lays the rows out anew.
+void plane::read_row_costs() {
+    _row_cost.assign(_y, 0);
+    for (std::size_t r = 0; r < _ctx.size(); ++r) {
+        const int n = _blocks[r].second;
+        if (n <= 0) continue;
+        const int rc = c5_get_row_costs(_ctx[r], _row_cost.data() + _blocks[r].first, n);
+        if (rc == C5_RETRY) _retry_seen[r] = 1;  // (the costs are of an earlier, complete frame; the frames in flight are not)
+        else check(rc, "c5_get_row_costs", r);
+    }
+    const double base = kRowBaseCost * static_cast<double>(_x);
+    const std::vector<std::pair<int, int>> want = balanced_row_blocks(_row_cost, static_cast<int>(_ctx.size()), base);
+    auto dearest = [&](const std::vector<std::pair<int, int>>& blocks) {
+        double top = 0.0;
+        for (const auto& b : blocks) {
+            double c = base * b.second;
+            for (int k = 0; k < b.second; ++k) c += _row_cost[static_cast<std::size_t>(b.first + k)];
+            top = std::max(top, c);
+        }
+        return top;
+    };
+    if (want != _blocks && dearest(_blocks) > kRebalanceGain * dearest(want)) {
+        _wanted_blocks = want;
+        _rebalance_due = true;
+    }
+}
+
+void plane::apply_blocks(const std::vector<std::pair<int, int>>& blocks) {
+    for (std::size_t r = 0; r < _ctx.size(); ++r) {
+        int rc = c5_set_row_range(_ctx[r], blocks[r].first, blocks[r].second);
+        if (rc == C5_RETRY) rc = C5_OK;  // nothing is in flight here: a retry belongs to frames already completed again
+        check(rc, "c5_set_row_range", r);
+        if (_mg) _mg->n_rows[r] = blocks[r].second;
+    }
+    _blocks = blocks;
+    ++_rebalances;
+}
+
+// rccl / p2p: every strip is known complete (status checked) before anything is exchanged; every block (tile) lands
 // at its final offset of the root GPU's image; one copy from there to the host.
 void plane::finish_exchange(frame_t& f) {
     multi_gpu& m = *_mg;
     const int world = static_cast<int>(_ctx.size());
+    const bool blocks = world > 1 && _layout == row_layout::blocks;
+    const std::size_t row_floats = _x * 2, tile_floats = row_floats * kTileRows;
+    const std::size_t row_bytes = row_floats * sizeof(float), tile_bytes = tile_floats * sizeof(float);
+    auto target_of = [&](std::size_t r) { return (blocks && r == 0) ? m.root_frame + static_cast<std::size_t>(_blocks[0].first) * row_floats : m.strip[r]; };
     for (std::size_t r = 0; r < _ctx.size(); ++r) {
         int rc = c5_synchronize(_ctx[r]);
+        if (_retry_seen[r]) {  // stats() ran into the retry first (and with it cleared the library's own note of it)
+            _retry_seen[r] = 0;
+            if (rc == C5_OK) rc = C5_RETRY;
+        }
         for (int attempt = 0; rc == C5_RETRY && attempt < 3; ++attempt) {  // an internal buffer grew: this device renders again
             ++_retries;
-            check(c5_render_device(_ctx[r], m.strip[r]), "trace_rays", r);
+            send_views(f.views);
+            check(c5_render_device(_ctx[r], target_of(r)), "trace_rays", r);
             rc = c5_synchronize(_ctx[r]);
+            send_views(_views);
         }
         check(rc, "trace_rays", r);
     }
-    const std::size_t row_floats = _x * 2, tile_floats = row_floats * kTileRows;
-    const std::size_t row_bytes = row_floats * sizeof(float), tile_bytes = tile_floats * sizeof(float);
     const int n_tiles = static_cast<int>((_y + kTileRows - 1) / kTileRows);
     auto rows_of_tile = [&](int gt) { return std::min<std::size_t>(kTileRows, _y - static_cast<std::size_t>(gt) * kTileRows); };
     auto copy_own_tiles = [&](std::size_t r, hipStream_t s) {  // 2-D copy: one "row" of it = one tile
@@ -467,24 +629,44 @@ void plane::finish_exchange(frame_t& f) {
     if (_exchange == exchange_mode::rccl && m.rccl_ready) {
         rccl_api& nccl = rccl_api::get();
         ncclResult_t rc = nccl.GroupStart();
-        for (int gt = 0; gt < n_tiles && rc == ncclSuccess; ++gt) {
-            const int r = gt % world, lt = gt / world;
-            if (r == 0) continue;
-            const std::size_t count = rows_of_tile(gt) * row_floats;
-            rc = nccl.Send(m.strip[static_cast<std::size_t>(r)] + tile_floats * lt, count, ncclFloat, 0,
-                          m.comm[static_cast<std::size_t>(r)], m.stream[static_cast<std::size_t>(r)]);
-            if (rc == ncclSuccess)
-                rc = nccl.Recv(m.root_frame + tile_floats * gt, count, ncclFloat, r, m.comm[0], m.stream[0]);
+        if (blocks) {
+            // ONE message per GPU and frame: peer r's block, contiguous in the image, received at its
+            // final offset of the root's image; the root receives from all its peers at once (7 xGMI links)
+            for (int r = 1; r < world && rc == ncclSuccess; ++r) {
+                const std::size_t count = static_cast<std::size_t>(_blocks[static_cast<std::size_t>(r)].second) * row_floats;
+                if (count == 0) continue;
+                rc = nccl.Send(m.strip[static_cast<std::size_t>(r)], count, ncclFloat, 0, m.comm[static_cast<std::size_t>(r)], m.stream[static_cast<std::size_t>(r)]);
+                if (rc == ncclSuccess)
+                    rc = nccl.Recv(m.root_frame + static_cast<std::size_t>(_blocks[static_cast<std::size_t>(r)].first) * row_floats, count, ncclFloat, r,
+                                   m.comm[0], m.stream[0]);
+            }
+        } else {
+            for (int gt = 0; gt < n_tiles && rc == ncclSuccess; ++gt) {
+                const int r = gt % world, lt = gt / world;
+                if (r == 0) continue;
+                const std::size_t count = rows_of_tile(gt) * row_floats;
+                rc = nccl.Send(m.strip[static_cast<std::size_t>(r)] + tile_floats * lt, count, ncclFloat, 0,
+                              m.comm[static_cast<std::size_t>(r)], m.stream[static_cast<std::size_t>(r)]);
+                if (rc == ncclSuccess)
+                    rc = nccl.Recv(m.root_frame + tile_floats * gt, count, ncclFloat, r, m.comm[0], m.stream[0]);
+            }
         }
         const ncclResult_t end = nccl.GroupEnd();
         if (rc != ncclSuccess || end != ncclSuccess)
             throw std::runtime_error(std::string("RCCL exchange failed: ") + nccl.GetErrorString(rc != ncclSuccess ? rc : end));
         hip_check(hipSetDevice(_devices[0]), "hipSetDevice");
-        copy_own_tiles(0, m.stream[0]);
+        if (!blocks) copy_own_tiles(0, m.stream[0]);
     } else {
         for (std::size_t r = 0; r < _ctx.size(); ++r) {
             hip_check(hipSetDevice(_devices[r]), "hipSetDevice");
-            copy_own_tiles(r, m.stream[r]);  // runs on the sending device's stream, writes the root's memory
+            if (blocks) {
+                if (r == 0) continue;  // rendered in place
+                // one peer copy per GPU, on the sending device's stream, into the root's memory
+                hip_check(hipMemcpyAsync(m.root_frame + static_cast<std::size_t>(_blocks[r].first) * row_floats, m.strip[r],
+                                         row_bytes * static_cast<std::size_t>(_blocks[r].second), hipMemcpyDeviceToDevice, m.stream[r]), "hipMemcpyAsync (peer)");
+            } else {
+                copy_own_tiles(r, m.stream[r]);  // runs on the sending device's stream, writes the root's memory
+            }
             if (r > 0) hip_check(hipEventRecord(m.done[r], m.stream[r]), "hipEventRecord");
         }
         hip_check(hipSetDevice(_devices[0]), "hipSetDevice");
@@ -495,41 +677,54 @@ void plane::finish_exchange(frame_t& f) {
     hip_check(hipStreamSynchronize(m.stream[0]), "hipStreamSynchronize");
 }
 
+// Wait for the oldest frame in flight; on C5_RETRY (an internal buffer was too small: that frame and every frame
+// enqueued since are suspect on every device) let them all finish, then render them again, in order, each with its
+// own views.
+void plane::complete_front() {
+    if (_exchange != exchange_mode::host) {
+        finish_exchange(_flight.front());
+        return;
+    }
+    for (int attempt = 0;; ++attempt) {
+        bool retry = false;
+        for (std::size_t r = 0; r < _ctx.size(); ++r) {
+            const int rc = c5_render_host_wait(_ctx[r]);
+            if (rc == C5_RETRY)
+                retry = true;
+            else
+                check(rc, "trace_rays", r);
+        }
+        if (retry_seen()) retry = true;  // stats() / the row-cost read met the retry before this wait did
+        if (!retry) break;
+        if (attempt >= 3) throw std::runtime_error("trace_rays: frames kept being reported incomplete");
+        ++_retries;
+        for (std::size_t k = 1; k < _flight.size(); ++k)
+            for (std::size_t r = 0; r < _ctx.size(); ++r) {
+                const int rc = c5_render_host_wait(_ctx[r]);
+                if (rc != C5_RETRY) check(rc, "trace_rays", r);
+            }
+        (void)retry_seen();
+        for (frame_t& f : _flight) {
+            send_views(f.views);
+            start(f);
+        }
+        send_views(_views);
+    }
+}
+
 object2d plane::trace_rays(tetra_value value_alpha, tetra_value value_Q) {
     if (value_alpha != tetra_value::alpha || value_Q != tetra_value::Q)
         throw std::runtime_error("trace_rays: only (alpha, Q) is supported");
-    if (_flight.empty()) find_intersections();
-    if (_exchange != exchange_mode::host) {
-        finish_exchange(_flight.front());
-    } else {
-        for (int attempt = 0;; ++attempt) {
-            bool retry = false;
-            for (std::size_t r = 0; r < _ctx.size(); ++r) {
-                const int rc = c5_render_host_wait(_ctx[r]);
-                if (rc == C5_RETRY)
-                    retry = true;
-                else
-                    check(rc, "trace_rays", r);
-            }
-            if (!retry) break;
-            // An internal buffer was too small for this frame: it and every frame enqueued since are suspect
-            // on every device.  Let them all finish, then render them again, in order, each with its own views.
-            if (attempt >= 3) throw std::runtime_error("trace_rays: frames kept being reported incomplete");
-            ++_retries;
-            for (std::size_t k = 1; k < _flight.size(); ++k)
-                for (std::size_t r = 0; r < _ctx.size(); ++r) {
-                    const int rc = c5_render_host_wait(_ctx[r]);
-                    if (rc != C5_RETRY) check(rc, "trace_rays", r);
-                }
-            for (frame_t& f : _flight) {
-                send_views(f.views);
-                start(f);
-            }
-            send_views(_views);
-        }
+    if (!_parked.empty()) {  // completed while the rows were laid out anew
+        frame_t f = std::move(_parked.front());
+        _parked.pop_front();
+        return object2d(std::move(f.image), _x, _y);
     }
+    if (_flight.empty()) find_intersections();
+    complete_front();
     frame_t f = std::move(_flight.front());
     _flight.pop_front();
+    if (f.probe) read_row_costs();
     return object2d(std::move(f.image), _x, _y);
 }
 
@@ -538,7 +733,13 @@ c5_stats plane::stats() {
     for (std::size_t r = 0; r < _ctx.size(); ++r) {
         c5_stats st{};
         int rc = c5_get_stats(_ctx[r], &st);
-        if (rc == C5_RETRY) rc = C5_OK;  // frames in flight behind the last completed one: theirs to report
+        if (rc == C5_RETRY) {
+            // An internal buffer was too small for a frame since the last look, and by reporting it here the
+            // library has settled it (pool grown, failure words cleared).  The counts are still those of the last
+            // frame; the frames in flight are incomplete and the next trace_rays renders them again.
+            _retry_seen[r] = 1;
+            rc = C5_OK;
+        }
         check(rc, "c5_get_stats", r);
         sum.segments += st.segments;
         sum.covered_pixels += st.covered_pixels;

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <deque>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -15,6 +16,9 @@
 #include "scene.hpp"
 
 // Pinned host images, recycled: a 2400x1800 frame is 34.6 MB, and pinning memory costs milliseconds.
+// Portable pinned memory (hipHostMallocPortable): with several GPUs every device's copy engine writes its rows into
+// the same image.  take() and the hand-back may run on different threads (a frame is handed back by whoever lets
+// go of it last: the thread that writes the file).
 class image_pool : public std::enable_shared_from_this<image_pool> {
 public:
     explicit image_pool(std::size_t bytes) : _bytes(bytes) {}
@@ -24,6 +28,7 @@ public:
 
 private:
     std::size_t _bytes;
+    std::mutex _lock;
     std::vector<float*> _free;
 };
 
@@ -60,6 +65,14 @@ private:
 //   p2p   the same exchange as peer-to-peer 2-D copies (hipMemcpy2DAsync, the copy engines instead of a kernel).
 enum class exchange_mode { host, rccl, p2p };
 
+// Which rows a GPU renders when several share a frame:
+//   blocks  ONE contiguous block of rows per GPU, sized by measured cost (segments per row of an earlier frame +
+//           a base cost per pixel): a block is contiguous in the [y][x][2] image, so it travels as ONE message /
+//           ONE copy per GPU and frame and lands at its final offset; every GPU builds only the records its rays
+//           can reach.  The default.  Re-measured every kProbeEvery frames of a sweep, moved when it pays.
+//   tiles   cyclic tiles of 16 rows (tile t -> GPU t mod N): balanced by construction, one message per tile.
+enum class row_layout { blocks, tiles };
+
 struct multi_gpu;  // RCCL communicators, peer access, per-device strips (plane.cpp)
 
 class plane {
@@ -71,7 +84,7 @@ public:
     // each; with more than one the image rows are dealt to them in cyclic tiles of 16 rows.
     explicit plane(std::size_t res_x, std::size_t res_y, std::vector<object3d_base> objects3d,
                    std::vector<double> global_boundaries = {}, std::vector<int> devices = {0},
-                   exchange_mode exchange = exchange_mode::host);
+                   exchange_mode exchange = exchange_mode::host, row_layout layout = row_layout::blocks);
     ~plane();
     plane(const plane&) = delete;
     plane& operator=(const plane&) = delete;
@@ -86,26 +99,40 @@ public:
 
     std::size_t get_x() const { return _x; }
     std::size_t get_y() const { return _y; }
-    std::size_t frames_in_flight() const { return _flight.size(); }
+    std::size_t frames_in_flight() const { return _flight.size() + _parked.size(); }
     std::size_t retries() const { return _retries; }
 
-    // Re-send the objects' rotation lists (a sweep changes only these; the grid stays on the GPU).
-    void update_views(std::vector<object3d_base>& objects3d);
-    c5_stats stats();  // of the last completed frame: counts summed over the devices, times of the slowest
-
-private:
     struct views_t {
         std::vector<c5_rotation> grid;
         std::vector<std::vector<c5_rotation>> solids;  // by solid slot
     };
+    // Re-send the objects' rotation lists (a sweep changes only these; the grid stays on the GPU).
+    void update_views(std::vector<object3d_base>& objects3d) { set_views(views_of(objects3d)); }
+    // The same in two steps, for drivers that work the angles out on one thread and issue frames on another
+    // (views_of reads the objects and nothing of the plane that changes after its construction).
+    views_t views_of(std::vector<object3d_base>& objects3d) const;
+    void set_views(const views_t& v);
+    // of the last completed frame: counts summed over the devices, times of the slowest.  May be called with frames
+    // in flight: a C5_RETRY it runs into (an internal buffer grew) is remembered and honoured by the next trace_rays.
+    c5_stats stats();
+    // the rows [begin, begin + count) every device renders (blocks layout) — for logs and tests
+    std::vector<std::pair<int, int>> row_blocks() const { return _blocks; }
+    std::size_t rebalances() const { return _rebalances; }
+
+private:
     struct frame_t {
         std::shared_ptr<float> image;
         views_t views;
+        bool probe = false;  // the walk counted segments per row for this frame (blocks layout)
     };
     void check(int rc, const char* what, std::size_t dev = 0);
     void send_views(const views_t& v);
     void start(frame_t& f);                 // enqueue on every device
     void finish_exchange(frame_t& f);       // rccl / p2p: strips -> root image -> host (synchronous)
+    void complete_front();                  // wait for the oldest frame in flight (renders again on C5_RETRY)
+    void read_row_costs();                  // after a probe frame: costs of all rows, and whether other blocks would pay
+    void apply_blocks(const std::vector<std::pair<int, int>>& blocks);
+    bool retry_seen();                      // any device's stats() ran into C5_RETRY since the last look (cleared)
     std::vector<c5_context*> _ctx;
     std::vector<int> _devices;
     exchange_mode _exchange = exchange_mode::host;
@@ -113,9 +140,16 @@ private:
     std::vector<int> _slot_of_object;  // -1: part of the volume grid, >= 0: solid slot
     views_t _views;
     std::deque<frame_t> _flight;
+    std::deque<frame_t> _parked;  // completed ahead of their trace_rays (a rebalance drained the frames in flight)
     std::shared_ptr<image_pool> _pool;
     std::unique_ptr<multi_gpu> _mg;
     std::size_t _retries = 0;
+    row_layout _layout = row_layout::blocks;
+    std::vector<std::pair<int, int>> _blocks, _wanted_blocks;  // per device: first row, rows
+    std::vector<uint32_t> _row_cost;                           // segments per image row of the last probe frame
+    std::vector<char> _retry_seen;
+    std::size_t _issued = 0, _rebalances = 0;
+    bool _rebalance_due = false;
 };
 
 // {x_max, x_min, y_max, y_min} of the objects' transformed vertices: what the reference's plane uses when no
@@ -123,10 +157,16 @@ private:
 std::array<double, 4> bounding_box(std::vector<object3d_base>& objects3d);
 
 // What a one-GPU box can check of the RCCL exchange: librccl loads, every entry point the exchange uses resolves,
-// a communicator comes up (ncclCommInitAll over the one device), and the exchange's own call pattern — a group of
-// ncclSend / ncclRecv pairs that land 16-row tiles at their final offsets of a frame — moves the right bytes, the
-// device sending to itself.  Returns a line for the log; throws on any failure.
+// a communicator comes up (ncclCommInitAll over the one device), and the exchange's own call patterns — (tiles) a
+// group of ncclSend / ncclRecv pairs that land 16-row tiles at their final offsets of a frame, (blocks) ONE pair per
+// peer landing a whole block of rows at its offset — move the right bytes, the device sending to itself.  Returns a
+// line for the log; throws on any failure.
 std::string rccl_selftest(int device);
+
+// Contiguous blocks of (nearly) equal cost: cost of a row = its segments + base_cost_per_pixel * res_x (the work
+// every pixel costs regardless: entry lookup, store).  Every device gets at least one row.  The same partition
+// course5_amd/sharding.py: balanced_blocks computes (tests compare the two).
+std::vector<std::pair<int, int>> balanced_row_blocks(const std::vector<uint32_t>& row_cost, int world, double base_cost_per_row);
 
 // "0", "0-7", "0,2,4", "0,0" (the same GPU twice: rehearsal of the multi-GPU path on one GPU)
 std::vector<int> parse_device_list(const std::string& text);

@@ -112,11 +112,13 @@ def _run(args, timeout=600):
     return r
 
 
+@pytest.mark.parametrize("layout", ["tiles", "blocks"])
 @pytest.mark.parametrize("exchange", ["host", "p2p", "rccl"])
-def test_course_splits_a_frame_by_rows_over_several_contexts(tmp_path, exchange):
-    """`course --devices`: one process, one c5_context per listed GPU, cyclic 16-row tiles, every tile
+def test_course_splits_a_frame_by_rows_over_several_contexts(tmp_path, exchange, layout):
+    """`course --devices`: one process, one c5_context per listed GPU; rows in cyclic 16-row tiles or in one
+    contiguous block per GPU (a single frame has no earlier frame to measure: equal blocks), every tile / block
     delivered at its final offset (host: each GPU copies its rows into the pinned host image; p2p / rccl:
-    into the root GPU's image first).  The test box has one GPU, so the list names it three times: everything
+    into the root GPU's image first; with blocks the root renders its own block in place).  The test box has one GPU, so the list names it three times: everything
     runs except the RCCL transport itself, which refuses duplicate devices — the run must say so and fall
     back to peer copies.  Output equals the single-GPU file value for value; 450 rows leave a short last tile."""
     xyz, cells, a, q = mg.workload("c2")
@@ -124,7 +126,8 @@ def test_course_splits_a_frame_by_rows_over_several_contexts(tmp_path, exchange)
     mg.write_vtk_binary(str(src), xyz, cells, a, q)
     common = ["-f", src, "-x", 600, "-y", 450, "-X", 0.1, "-Y", 0.07, "-D", 0.3, "--raw_vti", "-j4"]
     _run(common + ["-d", tmp_path / "one.vti"])
-    r = _run(common + ["-d", tmp_path / "many.vti", "--devices", "0,0,0", "--exchange", exchange, "--split", "rows", "--stats"])
+    r = _run(common + ["-d", tmp_path / "many.vti", "--devices", "0,0,0", "--exchange", exchange, "--split", "rows",
+                       "--row_layout", layout, "--stats"])
     one, _ = vtkio.read_vti(str(tmp_path / "one.vti"))
     many, _ = vtkio.read_vti(str(tmp_path / "many.vti"))
     assert np.array_equal(one, many, equal_nan=True)
@@ -133,6 +136,31 @@ def test_course_splits_a_frame_by_rows_over_several_contexts(tmp_path, exchange)
         assert "exchanging by peer copies instead" in r.stderr
     segs = [int(w) for line in r.stdout.splitlines() if "segments" in line for w in [line.split(";")[1].split()[0]]]
     assert segs and segs[0] > 0
+
+
+@pytest.mark.parametrize("exchange", ["host", "p2p"])
+def test_course_sweep_in_cost_balanced_row_blocks(tmp_path, exchange):
+    """`--split rows` of a sweep: ONE contiguous block of rows per GPU (one message / copy per GPU and
+    frame), equal blocks for the first frame, then sized by the segments per row the walk counted (probe frames) —
+    the ball sits in the middle of the image, so equal blocks are badly unbalanced and the rows MUST move; frames
+    are issued ahead, so the move happens with frames in flight.  Every file equals the single-context one."""
+    xyz, cells, a, q = mg.workload("c2")
+    src = tmp_path / "c2.vtk"
+    mg.write_vtk_binary(str(src), xyz, cells, a, q)
+    common = ["-f", src, "-x", 500, "-y", 375, "-X", 0.1, "-Y", 0.07, "-D", 0.2, "--frames", 9, "--sweep", "Y",
+              "--sweep_step", 0.04, "--raw_vti", "-j4", "--stats"]
+    _run(common + ["-d", tmp_path / "one.vti"])
+    r = _run(common + ["-d", tmp_path / "blk.vti", "--devices", "0,0,0", "--split", "rows", "--exchange", exchange])
+    for k in range(9):
+        one, _ = vtkio.read_vti(str(tmp_path / f"one_{k:05d}.vti"))
+        blk, _ = vtkio.read_vti(str(tmp_path / f"blk_{k:05d}.vti"))
+        assert np.array_equal(one, blk, equal_nan=True), k
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("Row blocks laid out anew")]
+    assert line, r.stdout[-800:]
+    moved = int(line[0].split(":")[1].split(";")[0])
+    rows = [int(w) for w in line[0].rsplit(":", 1)[1].split()]
+    assert moved >= 1 and sum(rows) == 375 and len(rows) == 3
+    assert rows[1] < rows[0] and rows[1] < rows[2]  # the block through the ball is the thinnest
 
 
 def test_course_deals_the_frames_of_a_sweep_to_several_contexts(tmp_path):
@@ -167,7 +195,16 @@ def test_course_bench_prints_one_json_line(tmp_path):
         assert len(line) == 1
         b = json.loads(line[0])["course_bench"]
         assert b["frames"] == 30 and b["split"] == split and b["mrays_per_s"] > 10 and b["retries"] == 0
+        assert b["row_layout"] == ("blocks" if split == "rows" else "none")
         assert not list(tmp_path.glob("*.vti"))
+    # --bench_files: the timed frames are written like a sweep's (the end-to-end figure with files)
+    r = _run(["-f", src, "-d", tmp_path / "bf.vti", "-x", 640, "-y", 480, "-X", 0.1, "-Y", 0.07, "--no_solids", "--bench", 6,
+              "--bench_warmup", 2, "--bench_files", "--sweep", "Y", "-j4"])
+    b = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"course_bench"')][0])["course_bench"]
+    assert b["delivered_to"] == "zlib .vti files" and b["frames_per_s"] > 1
+    assert len(list(tmp_path.glob("bf_*.vti"))) == 6
+    img, _ = vtkio.read_vti(str(tmp_path / "bf_00003.vti"))
+    assert img.shape == (480, 640, 2) and (img[..., 0] > 0).sum() > 10_000
 
 
 def test_course_automatic_boundaries(tmp_path, oracle_port):
@@ -216,14 +253,25 @@ def test_course_sweep_survives_a_starved_entry_pool(tmp_path):
         calm, _ = vtkio.read_vti(str(tmp_path / f"calm_{k:05d}.vti"))
         starved, _ = vtkio.read_vti(str(tmp_path / f"starved_{k:05d}.vti"))
         assert np.array_equal(calm, starved), k
-    for devices in ("0,0",):  # the same with the rows of every frame split over two contexts
-        r = subprocess.run([COURSE] + [str(x) for x in common + ["-d", tmp_path / "two.vti", "--devices", devices, "--split", "rows"]],
-                           capture_output=True, text=True, timeout=600, env=env)
-        assert r.returncode == 0, r.stderr[-1000:]
+    # the same with the rows of every frame split over two contexts, tiles and blocks, host copies and peer copies —
+    # and with count_all_intersections() called between find_intersections() and trace_rays() (C5_TEST_STATS_BETWEEN:
+    # the reference's API allows it, plane.cpp:3-12): the stats call then meets the C5_RETRY first, the library
+    # settles it there (pool grown, failure words cleared), and trace_rays must still render the frames again
+    # (plane.cpp:541 swallowed it)
+    runs = [("0,0", "tiles", "host", False), ("0,0", "blocks", "host", False), ("0,0", "blocks", "host", True),
+            ("0,0", "blocks", "p2p", True), ("0,0", "tiles", "p2p", True), ("0", "blocks", "host", True)]
+    for n, (devices, layout, exchange, between) in enumerate(runs):
+        e2 = dict(env, C5_TEST_STATS_BETWEEN="1") if between else env
+        extra = ["--devices", devices, "--split", "rows", "--row_layout", layout, "--exchange", exchange] if devices != "0" else []
+        r = subprocess.run([COURSE] + [str(x) for x in common + ["-d", tmp_path / f"r{n}.vti"] + extra],
+                           capture_output=True, text=True, timeout=600, env=e2)
+        assert r.returncode == 0, (runs[n], r.stderr[-1000:])
+        again = [int(line.rsplit(":", 1)[1]) for line in r.stdout.splitlines() if line.startswith("Frames rendered again")]
+        assert again and again[0] >= 1, runs[n]
         for k in range(6):
             calm, _ = vtkio.read_vti(str(tmp_path / f"calm_{k:05d}.vti"))
-            two, _ = vtkio.read_vti(str(tmp_path / f"two_{k:05d}.vti"))
-            assert np.array_equal(calm, two), k
+            got, _ = vtkio.read_vti(str(tmp_path / f"r{n}_{k:05d}.vti"))
+            assert np.array_equal(calm, got), (runs[n], k)
 
 
 def test_course_sweep_writes_colour_mapped_frames(tmp_path):
@@ -260,3 +308,4 @@ def test_rccl_entry_points_and_call_pattern_on_one_gpu():
     r = subprocess.run([COURSE, "--rccl_selftest"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
     assert "RCCL self-test ok" in r.stdout and "5 grouped ncclSend/ncclRecv pairs" in r.stdout
+    assert "2 pairs (one per peer)" in r.stdout  # the blocks layout: one message per GPU and frame
