@@ -58,9 +58,15 @@ def parse():
     p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--workload", default="c3", help="c3 (998 250 tets, default), c2, kuhnN")
     p.add_argument("--res", default="2400x1800", help="image size of the N = 1 workload")
-    p.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                   help="N > 1: weak = per-GPU rays stay at --res (image grows by sqrt(N) per side; N = 4 is "
-                        "BASELINE config 4, 4800x3600); strong = the same --res frame split over N GPUs")
+    p.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                   help="N > 1: strong (default) = the same --res frame split over N GPUs: north_star's \">= 6x at 8 GPUs on "
+                        "row-tile split\" clause, and the workload of the N = 1 line, so that value(N) / value(1) is a "
+                        "speed-up; weak = per-GPU rays stay at --res (the image grows by sqrt(N) per side)")
+    p.add_argument("--no-configs", action="store_true",
+                   help="N > 1: skip the figures of BASELINE configs 4 (4800x3600 split by rows) and 5 (360-frame -D sweep "
+                        "with solids, whole frames dealt to the GPUs) that follow the headline")
+    p.add_argument("--config4-res", default="4800x3600", help="image size of the config-4 figure")
+    p.add_argument("--config5-frames", type=int, default=360, help="frames of the config-5 sweep (D = k / 180)")
     p.add_argument("--mode", choices=["rows", "frames"], default="rows",
                    help="N > 1: rows = every frame is split by rows over the ranks and exchanged (config 4); "
                         "frames = frame k of a sweep is rendered whole by rank k mod N, no exchange (config 5)")
@@ -132,6 +138,22 @@ def load_roofline_counters():
         return None
 
 
+def predicted_scaling(res_x, res_y, world):
+    """What row-splitting this frame over `world` GPUs can give at best: every rank's share of the frame timed in turn
+    on ONE GPU (scripts/sim_scaling.py -> profiles/sim_scaling.json; no exchange, no second GPU involved)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "sim_scaling.json")) as f:
+            sim = json.load(f)
+        e = sim["frames"][f"{res_x}x{res_y}"]["world"][str(world)]
+        return {"speedup": e["blocks"]["speedup"], "slowest_rank_ms": e["blocks"]["max_ms"], "one_gpu_ms": sim["frames"][f"{res_x}x{res_y}"]["full_ms"],
+                "cyclic_speedup": e["cyclic"]["speedup"],
+                "what": "per-rank GPU times of the balanced blocks measured one after the other on one GPU "
+                        f"({sim.get('round', '?')}, scripts/sim_scaling.py): a ray is a chain of ~130 dependent steps, so a "
+                        "rank's time does not fall in proportion to its rows; exchange not included"}
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def product_solids():
     import subprocess
     import tempfile
@@ -163,7 +185,7 @@ def native_course_bench(xyz, cells, alpha, q, res_x, res_y, n_devices, frames, w
             mg.write_vtk_binary(src, xyz, cells, alpha, q, v51=True)
             devs = ",".join(str(k) for k in range(n_devices)) if not os.environ.get("C5_BENCH_ONE_DEVICE") else ",".join(["0"] * n_devices)
             for name, extra in variants:
-                cmd = [exe, "-f", src, "--no_solids", "-x", str(res_x), "-y", str(res_y), "-X", str(mg.BENCH_VIEW["angle_around_x"]),
+                cmd = [exe, "-f", src, "-d", os.path.join(d, "frame.vti"), "--no_solids", "-x", str(res_x), "-y", str(res_y), "-X", str(mg.BENCH_VIEW["angle_around_x"]),
                        "-Y", str(mg.BENCH_VIEW["angle_around_y"]), "--bench", str(frames), "--bench_warmup", str(warmup),
                        "--sweep", "Y", "--sweep_step", "0", "--devices", devs] + extra
                 try:
@@ -226,7 +248,6 @@ def main():
     if args.pipeline >= 0:
         ctx.set_option("pipeline", args.pipeline)
     ctx.upload_grid(xyz, cells, alpha, q)
-    ctx.set_image(res_x, res_y, mg.REFERENCE_BOUNDS)
     ctx.set_view(rots)
     ctx.set_alpha_limit(2.5)
     ctx.set_option("stage_timing", 0)
@@ -241,134 +262,206 @@ def main():
     if not args.own_stream:
         ctx.set_stream(stream.cuda_stream)
 
+    soups = None
+
+    def put_solids(on: bool):
+        nonlocal soups
+        if on:
+            if soups is None:
+                soups = product_solids()
+            ctx.set_solid(0, soups[0])
+            ctx.set_solid(1, soups[1])
+            ctx.set_solid_view(1, np.zeros((0, 3)))  # the sphere is never rotated (main.cpp:116)
+            ctx.set_solid_view(0, np.vstack([[1.0, 0.0, 1.0], rots]))
+        else:
+            ctx.set_solid(0, np.zeros((0, 12)))
+            ctx.set_solid(1, np.zeros((0, 12)))
+
     if args.solids:
-        soups = product_solids()
-        ctx.set_solid(0, soups[0])
-        ctx.set_solid(1, soups[1])
-        ctx.set_solid_view(1, np.zeros((0, 3)))  # the sphere is never rotated (main.cpp:116)
-        ctx.set_solid_view(0, np.vstack([[1.0, 0.0, 1.0], rots]))
+        put_solids(True)
 
     # frame k of a sweep: in frame-parallel mode rank r renders frames r, r + N, r + 2N, ...
-    sweep_k = [rank if frame_parallel else 0]
-    sweep_stride = world if frame_parallel else 1
+    sweep = {"kind": args.sweep, "k": rank if frame_parallel else 0, "stride": world if frame_parallel else 1, "solids": bool(args.solids)}
 
     def advance_view():
-        if args.sweep == "none":
+        if sweep["kind"] == "none":
             return
-        ang = sweep_k[0] / 180.0
-        sweep_k[0] += sweep_stride
-        if args.sweep == "Y":
+        ang = sweep["k"] / 180.0
+        sweep["k"] += sweep["stride"]
+        if sweep["kind"] == "Y":
             r = mg.view_rotations(mg.BENCH_VIEW["angle_around_x"], mg.BENCH_VIEW["angle_around_y"] + ang)
             ctx.set_view(r)
-            if args.solids:
+            if sweep["solids"]:
                 ctx.set_solid_view(0, np.vstack([[1.0, 0.0, 1.0], r]))
-        elif args.solids:
+        elif sweep["solids"]:
             ctx.set_solid_view(0, np.vstack([[1.0, ang * 3.14159265358979323846, 1.0], rots]))
 
     def render(strip):
         advance_view()
         ctx.render_device(strip.data_ptr())
 
-    blocks = None
-    sharded = world > 1 and not frame_parallel
-    with torch.cuda.stream(stream):
-        if sharded and args.sharding == "cyclic":
+    def host_barrier():
+        """The ranks meet without touching the GPUs (an RCCL barrier is a kernel spinning on every GPU)."""
+        if world > 1:
+            dist.barrier(group=cpu_group) if cpu_group is not None else dist.barrier()
+
+    def lay_out_rows(rx, ry, split):
+        """Image size + which rows this rank renders.  Returns the blocks (None: cyclic tiles or the whole image)."""
+        ctx.set_row_tiles(0, 0, 1)
+        ctx.set_row_range(0, -1)
+        ctx.set_image(rx, ry, mg.REFERENCE_BOUNDS)
+        if not split:
+            return None
+        if args.sharding == "cyclic":
             ctx.set_row_tiles(TILE_ROWS, rank, world)
-        elif sharded:
-            # one probe frame on equal blocks measures segments per row; every rank then derives the
-            # same cost-balanced contiguous blocks (pixels are independent: plane.cpp:161-169)
-            eq = sharding.equal_blocks(res_y, world)
-            ctx.set_row_range(*eq[rank])
-            ctx.set_option("row_costs", 1)
-            probe = torch.zeros((eq[rank][1], res_x, 2), dtype=torch.float32, device=dev)
-            for _ in range(4):
-                render(probe)
-                if ctx.synchronize() == capi.C5_OK:
-                    break
-            costs = gather_row_costs(ctx.row_costs(), eq, rank, world, rdev)
-            blocks = sharding.balanced_blocks(costs, world, base_cost=res_x * args.row_base_cost)
-            ctx.set_option("row_costs", 0)
-            ctx.set_row_range(*blocks[rank])
-            del probe
-    n_local = ctx.local_rows
-    # N > 1, rows: no strip is exchanged before its render is known to be complete (FramePipeline.check): a
-    # C5_RETRY is settled by the rank it happened on, before its one exchange of the step, so the ranks
-    # never disagree on the number of collectives.  N = 1 / frames: frames run back to back and the status
-    # is read once after the timed region (a retry there re-times the region and is reported).
-    pipe = FramePipeline(res_x, res_y, rank, world if sharded else 1, dev, depth=args.pipeline_depth, tile_rows=TILE_ROWS,
-                         blocks=blocks, host_staging=args.backend != "nccl", check=ctx.synchronize if sharded else None)
-    retries = 0
-
-    def settle():
-        """After a burst without per-frame checks: wait, and render again while the library says C5_RETRY."""
-        nonlocal retries
-        pipe.drain()
+            return None
+        # one probe frame on equal blocks measures segments per row; every rank then derives the
+        # same cost-balanced contiguous blocks (pixels are independent: plane.cpp:161-169)
+        eq = sharding.equal_blocks(ry, world)
+        ctx.set_row_range(*eq[rank])
+        ctx.set_option("row_costs", 1)
+        probe = torch.zeros((eq[rank][1], rx, 2), dtype=torch.float32, device=dev)
         for _ in range(4):
+            render(probe)
             if ctx.synchronize() == capi.C5_OK:
-                return
-            retries += 1
-            pipe.step(render)
-            pipe.drain()
-        raise SystemExit("frames kept being reported incomplete (C5_RETRY)")
+                break
+        costs = gather_row_costs(ctx.row_costs(), eq, rank, world, rdev)
+        blocks = sharding.balanced_blocks(costs, world, base_cost=rx * args.row_base_cost)
+        ctx.set_option("row_costs", 0)
+        ctx.set_row_range(*blocks[rank])
+        del probe
+        return blocks
 
-    with torch.cuda.stream(stream):
-        for k in range(max(args.warmup, 1)):
-            pipe.step(render)
-            if k < 2 and not sharded:
-                settle()  # the first frames size the internal buffers
-        settle()
-        # clock-steadying frames (untimed, not counted in W): a 20-frame warm-up is 15 ms, far too short for
-        # the clocks to settle (round 1: 0.670 ms per walk in the driver's short run vs 0.606 sustained).
-        # Batches of 50 frames until the walk time of a batch is within 1 % of the one before (at most 2 s).
-        steady = []
-        if not args.no_steady:
+    def measure(rx, ry, steps, warmup, split, steadying):
+        """W warm-up frames (+ clock-steadying batches), then exactly `steps` frames between barriers +
+        torch.cuda.synchronize() on both sides; a C5_RETRY inside the region re-times it."""
+        with torch.cuda.stream(stream):
+            blocks = lay_out_rows(rx, ry, split)
+            n_local = ctx.local_rows
+            # rows split: no strip is exchanged before its render is known to be complete (FramePipeline.check): a
+            # C5_RETRY is settled by the rank it happened on, before its one exchange of the step, so the ranks
+            # never disagree on the number of collectives.  Whole frames: frames run back to back and the status
+            # is read once after the timed region (a retry there re-times the region and is reported).
+            pipe = FramePipeline(rx, ry, rank, world if split else 1, dev, depth=args.pipeline_depth, tile_rows=TILE_ROWS,
+                                 blocks=blocks, host_staging=args.backend != "nccl", check=ctx.synchronize if split else None)
+            retries = 0
+
+            def settle():
+                """After a burst without per-frame checks: wait, and render again while the library says C5_RETRY."""
+                nonlocal retries
+                pipe.drain()
+                for _ in range(4):
+                    if ctx.synchronize() == capi.C5_OK:
+                        return
+                    retries += 1
+                    pipe.step(render)
+                    pipe.drain()
+                raise SystemExit("frames kept being reported incomplete (C5_RETRY)")
+
+            k0 = sweep["k"]
+            for k in range(max(warmup, 1)):
+                pipe.step(render)
+                if k < 2 and not split:
+                    settle()  # the first frames size the internal buffers
+            settle()
+            # clock-steadying frames (untimed, not counted in W): a 20-frame warm-up is 15 ms, far too short for
+            # the clocks to settle (round 1: 0.670 ms per walk in the driver's short run vs 0.606 sustained).
+            # Batches of 50 frames until the walk time of a batch is within 1 % of the one before (at most 2 s).
+            steady = []
+            if steadying:
+                ctx.walk_kernel_ms(reset=True)
+                t_lim = time.perf_counter() + 2.0
+                while time.perf_counter() < t_lim:
+                    for _ in range(50):
+                        pipe.step(render)
+                    pipe.drain()
+                    ms, _ = ctx.walk_kernel_ms(reset=True)
+                    steady.append(ms)
+                    go_on = torch.tensor([0 if (len(steady) >= 2 and abs(steady[-1] - steady[-2]) <= 0.01 * steady[-1]) else 1],
+                                         dtype=torch.int64, device=rdev)
+                    if world > 1:  # every rank runs the same number of batches (they exchange in every step)
+                        dist.all_reduce(go_on)
+                    if int(go_on.item()) == 0:
+                        break
+                settle()
+            sweep["k"] = k0
+            stats = ctx.stats()
             ctx.walk_kernel_ms(reset=True)
-            t_lim = time.perf_counter() + 2.0
-            while time.perf_counter() < t_lim:
-                for _ in range(50):
+            for attempt in range(3):
+                if world > 1:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for k in range(steps):
                     pipe.step(render)
                 pipe.drain()
-                ms, _ = ctx.walk_kernel_ms(reset=True)
-                steady.append(ms)
-                if len(steady) >= 2 and abs(steady[-1] - steady[-2]) <= 0.01 * steady[-1]:
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                elapsed = time.perf_counter() - t0
+                # A frame that made an internal buffer grow (C5_RETRY) inside a region without per-frame checks
+                # invalidates that region on every rank: time the K steps again.  A hard error is an error.
+                rc = ctx.synchronize()
+                redo = torch.tensor([1 if rc == capi.C5_RETRY else 0], dtype=torch.int64, device=rdev)
+                if world > 1:
+                    dist.all_reduce(redo)
+                walk_ms, walk_launches = ctx.walk_kernel_ms(reset=True)
+                if int(redo.item()) == 0:
                     break
-            settle()
-        if args.sweep != "none":
-            sweep_k[0] = rank if frame_parallel else 0
-        stats = ctx.stats()
-        ctx.walk_kernel_ms(reset=True)
+                retries += 1
+                sweep["k"] = k0
+            else:
+                raise SystemExit("frames kept being re-rendered inside the timed region")
+            retries += pipe.retries
+        el = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
+        seg = torch.tensor([stats["segments"], n_local * rx, retries], dtype=torch.int64, device=rdev)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            dist.all_reduce(seg, op=dist.ReduceOp.SUM)
+        S_total, P_total, retries_total = (int(v) for v in seg.tolist())
+        return {"elapsed": float(el.item()), "steps": steps, "blocks": blocks, "n_local": n_local, "stats": stats,
+                "walk_ms": walk_ms, "walk_launches": walk_launches, "steady": steady, "S_total": S_total, "P_total": P_total,
+                "retries": retries_total}
 
-        for attempt in range(3):
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for k in range(args.steps):
-                pipe.step(render)
-            pipe.drain()
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            elapsed = time.perf_counter() - t0
-            # A frame that made an internal buffer grow (C5_RETRY) inside a region without per-frame checks
-            # invalidates that region on every rank: time the K steps again.  A hard error is an error.
-            rc = ctx.synchronize()
-            redo = torch.tensor([1 if rc == capi.C5_RETRY else 0], dtype=torch.int64, device=rdev)
-            if world > 1:
-                dist.all_reduce(redo)
-            walk_ms, walk_launches = ctx.walk_kernel_ms(reset=True)
-            if int(redo.item()) == 0:
-                break
-            retries += 1
-            if args.sweep != "none":
-                sweep_k[0] = rank if frame_parallel else 0
-        else:
-            raise SystemExit("frames kept being re-rendered inside the timed region")
-    retries += pipe.retries
+    def one_gpu_reference(rx, ry, frames):
+        """Rank 0 renders the WHOLE rx x ry frame alone, the other ranks wait on the host: the N = 1 time of the very
+        image the N ranks just shared, in the same process, clocks and run."""
+        host_barrier()
+        ms = None
+        if rank == 0:
+            with torch.cuda.stream(stream):
+                lay_out_rows(rx, ry, False)
+                whole = torch.zeros((ry, rx, 2), dtype=torch.float32, device=dev)
+                for _ in range(3):
+                    for _ in range(20):
+                        render(whole)
+                    if ctx.synchronize() == capi.C5_OK:
+                        break
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(frames):
+                        render(whole)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                    if ctx.synchronize() == capi.C5_OK:
+                        break
+                ms = dt * 1e3 / frames
+                del whole
+        host_barrier()
+        return ms
+
+    sharded = world > 1 and not frame_parallel
+    head = measure(res_x, res_y, args.steps, args.warmup, sharded, not args.no_steady)
+    elapsed, stats, blocks, n_local = head["elapsed"], head["stats"], head["blocks"], head["n_local"]
+    walk_ms, walk_launches, steady, retries_total = head["walk_ms"], head["walk_launches"], head["steady"], head["retries"]
+    S_total, P_total = head["S_total"], head["P_total"]
+    k_ref = max(10, min(args.steps, 200))
+    head_one_gpu_ms = one_gpu_reference(res_x, res_y, k_ref) if sharded else None
 
     host_image = None
     if world == 1 and not args.no_host_image and hasattr(ctx, "render_host_async"):
-        host_image = ctx.bench_host_frames(min(args.steps, 100))
+        host_image = ctx.bench_host_frames(max(100, min(args.steps, 400)))
 
     # Second figure: the same frames with option "precision" 1 (fp32 face planes about a cell-local lattice origin,
     # fp64 accumulators; every parity test of tests/test_gpu_mixed.py holds the 1e-5 bar).  Never the headline:
@@ -400,66 +493,116 @@ def main():
                              "a face steep against the rays evaluated in fp64 (scalar loads); within the 1e-5 bar on every "
                              "parity test, not bit-faithful"}
 
-    # N > 1, second figure: the other way to use N GPUs — whole 2400x1800 frames, frame k on rank k mod N, nothing
-    # exchanged (how a sweep is rendered: BASELINE config 5; utility/rotate_traces.py runs one process per frame).
-    frames_mode = None
-    if world > 1 and sharded:
+    # N > 1: BASELINE's other multi-GPU configurations, each beside the one-GPU time of the same work measured by rank 0
+    # in this run.  Config 4: ONE 4800x3600 frame of the C3 grid split by rows.  Config 5: the 360-frame -D sweep with
+    # the Roche lobe and the accretor sphere resident, whole frames dealt to the GPUs (frame k on rank k mod N, no
+    # exchange: utility/rotate_traces.py runs one process per frame).
+    config4 = config5 = None
+    if sharded and not args.no_configs and args.sweep == "none" and not args.solids:
+        c4x, c4y = (int(v) for v in args.config4_res.lower().split("x"))
+        k4 = max(10, min(args.steps, 100))
+        m4 = measure(c4x, c4y, k4, min(args.warmup, 10), True, False)
+        one4 = one_gpu_reference(c4x, c4y, max(5, k4 // 2))
+        ms4 = m4["elapsed"] * 1e3 / k4
+        config4 = {"what": f"BASELINE config 4: one {c4x}x{c4y} frame of the same grid split by rows over {world} GPUs, one exchange "
+                           "per frame to rank 0; STRONG scaling against the one-GPU time of the same image (rank 0 alone, same run)",
+                   "value": round(c4x * c4y * k4 / m4["elapsed"] / 1e6, 2), "unit": "Mrays/s", "ms_per_frame": round(ms4, 4),
+                   "frames": k4, "rows_per_rank": [n for _, n in m4["blocks"]] if m4["blocks"] else f"cyclic tiles of {TILE_ROWS} rows",
+                   "segments_per_frame": m4["S_total"], "retries": m4["retries"]}
+        if rank == 0 and one4:
+            config4.update(one_gpu_ms_per_frame=round(one4, 4), one_gpu_value=round(c4x * c4y / one4 / 1e3, 2),
+                           speedup_vs_one_gpu=round(one4 / ms4, 3))
+        # config 5
+        n5 = max(world, args.config5_frames)
+        per_rank = (n5 + world - 1) // world
         with torch.cuda.stream(stream):
-            ctx.set_row_range(0, -1)
-            ctx.set_row_tiles(0, 0, 1)
-            ctx.set_image(base_res[0], base_res[1], mg.REFERENCE_BOUNDS)
+            lay_out_rows(base_res[0], base_res[1], False)
+            put_solids(True)
             whole = torch.zeros((base_res[1], base_res[0], 2), dtype=torch.float32, device=dev)
-            for _ in range(3):
-                for _ in range(30):
-                    ctx.render_device(whole.data_ptr())
+            sweep.update(kind="D", solids=True, stride=world)
+
+            def sweep_frames(first, count, stride):
+                sweep["k"], sweep["stride"] = first, stride
+                for _ in range(count):
+                    render(whole)
+
+            for _ in range(3):  # sizes the buffers, fills the sphere's cached mask
+                sweep_frames(rank, 6, world)
                 if ctx.synchronize() == capi.C5_OK:
                     break
-            dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                ctx.render_device(whole.data_ptr())
-            torch.cuda.synchronize()
-            dist.barrier()
-            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=rdev)
-            ok = torch.tensor([0 if ctx.synchronize() == capi.C5_OK else 1], dtype=torch.int64, device=rdev)
-            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-            dist.all_reduce(ok)
-            frames_mode = {"value": round(base_res[0] * base_res[1] * args.steps * world / float(dt.item()) / 1e6, 2),
-                           "unit": "Mrays/s", "ms_per_frame_per_gpu": round(float(dt.item()) * 1e3 / args.steps, 4),
-                           "frames": args.steps * world, "incomplete_frames_reported": int(ok.item()),
-                           "what": f"whole {base_res[0]}x{base_res[1]} frames, {args.steps} per GPU, frame k on rank k mod N, "
-                                   "grid replicated, no exchange; images stay in HBM"}
+            for attempt in range(3):
+                dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                mine = len(range(rank, n5, world))
+                sweep_frames(rank, mine, world)
+                torch.cuda.synchronize()
+                dist.barrier()
+                dt5 = time.perf_counter() - t0
+                redo = torch.tensor([0 if ctx.synchronize() == capi.C5_OK else 1], dtype=torch.int64, device=rdev)
+                dist.all_reduce(redo)
+                if int(redo.item()) == 0:
+                    break
+            t5 = torch.tensor([dt5], dtype=torch.float64, device=rdev)
+            dist.all_reduce(t5, op=dist.ReduceOp.MAX)
+            dt5 = float(t5.item())
+            # one GPU: rank 0 alone renders as many frames of the same sweep as one rank just did
+            host_barrier()
+            one5 = None
+            if rank == 0:
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    sweep_frames(0, per_rank, 1)
+                    torch.cuda.synchronize()
+                    one5 = (time.perf_counter() - t0) * 1e3 / per_rank
+                    if ctx.synchronize() == capi.C5_OK:
+                        break
+            host_barrier()
+            sweep.update(kind=args.sweep, solids=bool(args.solids), stride=1, k=0)
+            put_solids(False)
+            del whole
+        rays5 = base_res[0] * base_res[1]
+        config5 = {"what": f"BASELINE config 5: {n5}-frame -D sweep (D = k / 180) at {base_res[0]}x{base_res[1]} with the Roche lobe "
+                           f"(130 560 tets) and the accretor sphere (522 242 tets) resident, whole frames dealt to {world} GPUs "
+                           "(frame k on rank k mod N), grid + solids uploaded once, no exchange; images stay in HBM",
+                   "value": round(rays5 * n5 / dt5 / 1e6, 2), "unit": "Mrays/s", "frames": n5, "frames_per_s": round(n5 / dt5, 1),
+                   "ms_per_frame_job": round(dt5 * 1e3 / n5, 4), "incomplete_frames_reported": int(redo.item())}
+        if rank == 0 and one5:
+            config5.update(one_gpu_ms_per_frame=round(one5, 4), one_gpu_frames_per_s=round(1e3 / one5, 1),
+                           speedup_vs_one_gpu=round(one5 / (dt5 * 1e3 / n5), 3))
+        with torch.cuda.stream(stream):  # back to the headline's layout (the native host below uses its own contexts)
+            lay_out_rows(res_x, res_y, False)
 
     # The C++ host on the same workload: rank 0 runs it as a child process on all N GPUs while the other ranks
     # idle at the barrier below (their GPUs are free: nothing of this job is running on them).
     native = None
     if not args.no_native and not args.solids and args.sweep == "none" and args.workload == "c3":
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier(group=cpu_group)
+        host_barrier()
         if rank == 0:
             k = max(20, min(args.steps, 200))
             if world == 1:
-                variants = [("one_gpu", [])]
+                # sweep_files: the reference's real workload end to end (utility/rotate_traces.py:16-21 renders 1 500
+                # frames of a -Y sweep to files): every timed frame rendered, copied to pinned memory, deflated and
+                # written as a zlib .vti by the writer thread while the next frames render
+                variants = [("one_gpu", []),
+                            ("sweep_files", ["--bench_files", "--sweep_step", "0.00555556", "--bench", str(max(20, min(args.steps, 120))),
+                                             "--bench_warmup", "5", "-j", str(usable_cpus())])]
             else:
                 variants = [("rows_host", ["--split", "rows", "--exchange", "host"]),
+                            ("rows_host_tiles", ["--split", "rows", "--exchange", "host", "--row_layout", "tiles"]),
                             ("rows_rccl", ["--split", "rows", "--exchange", "rccl"]),
+                            ("rows_rccl_tiles", ["--split", "rows", "--exchange", "rccl", "--row_layout", "tiles"]),
                             ("rows_p2p", ["--split", "rows", "--exchange", "p2p"]),
                             ("frames", ["--split", "frames"])]
             native = native_course_bench(xyz, cells, alpha, q, res_x, res_y, world, k, 20, variants)
-        if world > 1:
-            dist.barrier(group=cpu_group)
-
-    el = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
-    seg = torch.tensor([stats["segments"], n_local * res_x, retries], dtype=torch.int64, device=rdev)
-    wk = torch.tensor([walk_ms], dtype=torch.float64, device=rdev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(seg, op=dist.ReduceOp.SUM)
-        dist.all_reduce(wk, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-    S_total, P_total, retries_total = (int(v) for v in seg.tolist())
+            if world > 1 and not args.no_configs:
+                c4x, c4y = (int(v) for v in args.config4_res.lower().split("x"))
+                native["config4"] = native_course_bench(xyz, cells, alpha, q, c4x, c4y, world, max(10, k // 2), 10,
+                                                        [("rows_host", ["--split", "rows", "--exchange", "host"]),
+                                                         ("rows_rccl", ["--split", "rows", "--exchange", "rccl"])])
+        host_barrier()
 
     if rank == 0:
         frames = args.steps * (world if frame_parallel else 1)
@@ -474,8 +617,21 @@ def main():
                                             not args.solids and args.sweep == "none") else None
         hbm_bytes = pmc.get("hbm_bytes_per_launch") if pmc else None
         achieved = hbm_bytes / secs / 1e9 if (hbm_bytes and secs > 0) else None
+        # The counters and the phase clock were collected by separate profiling runs (scripts/collect_pmc.sh,
+        # scripts/stamp_walk.py) and committed; they describe the kernels of that moment.  The hash of the kernel
+        # sources they were taken from travels with them: if the sources have changed since, say so.
+        from course5_amd.build import kernel_source_hash
+        src_hash = kernel_source_hash()
+        pmc_stale = bool(pmc) and pmc.get("source_hash") != src_hash
+        phases = (pmc or {}).get("phases")
         roofline = {
-            "bound": "hbm", "kernel": "walk_composite",
+            # No unit of the chip is saturated by this kernel (units below, every fraction from rocprofv3 counters):
+            # what a step costs is its serial chain, so the bound that binds is latency, and the phase clock
+            # (profiles/r03_walk_phases.md) says in which phase the chain spends its cycles.  The HBM figures stay
+            # as the contract asks for them: achieved / peak / frac are HBM-side bytes per launch over the live
+            # kernel time against 8 TB/s.
+            "bound": "latency" if (pmc and not phases) else (f"latency: {phases['dominant']}" if phases else "hbm"),
+            "nearest_roofline": "hbm", "kernel": "walk_composite",
             "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
             "traffic": hbm_bytes,
@@ -484,6 +640,9 @@ def main():
             "kernel_ms_rocprofv3": (pmc or {}).get("kernel_ms_rocprofv3"),
             "limiter": (pmc or {}).get("limiter"),
             "units": (pmc or {}).get("units"),
+            "phases": phases,
+            "pmc_round": (pmc or {}).get("round"), "pmc_source_hash": (pmc or {}).get("source_hash"),
+            "source_hash": src_hash, "pmc_stale": pmc_stale,
             "contract": {
                 "what": "SURVEY.md section 8(d): algorithmic bytes (S x 144 B + P x 8 B) / kernel time. Not a fraction "
                         "of a hardware limit: the per-view records (160 MB) are re-read from L2 / Infinity Cache, "
@@ -505,7 +664,8 @@ def main():
             metric = (f"Mrays/sec, WEAK scaling: {base_res[0]}x{base_res[1]} rays per GPU, one {res_x}x{res_y} image "
                       f"split by rows over {world} GPUs (an N-fold value here is not north_star's fixed-frame speed-up)")
         else:
-            metric = f"Mrays/sec, STRONG scaling: one {res_x}x{res_y} frame split by rows over {world} GPUs"
+            metric = (f"Mrays/sec at {res_x}x{res_y} on 1M-tet grid, STRONG scaling: the N = 1 frame split by rows over {world} GPUs "
+                      f"(north_star's 1 -> 8 GPU clause)")
         out = {
             "metric": metric, "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -530,15 +690,29 @@ def main():
                        "frames_timed": frames},
             "roofline": roofline,
         }
+        if sharded and head_one_gpu_ms:
+            # the same image on ONE GPU (rank 0 alone, same run): what value(N) is a speed-up over
+            out["one_gpu"] = {"ms_per_frame": round(head_one_gpu_ms, 4), "value": round(rays / head_one_gpu_ms / 1e3, 2),
+                              "frames": k_ref, "what": f"rank 0 rendering the whole {res_x}x{res_y} frame alone, the other ranks idle"}
+            out["speedup_vs_one_gpu"] = round(head_one_gpu_ms / ms_per_step, 3)
+            pred = predicted_scaling(res_x, res_y, world)
+            if pred:
+                out["predicted"] = pred
+        if config4 is not None:
+            pred = predicted_scaling(*(int(v) for v in args.config4_res.lower().split("x")), world)
+            if pred:
+                config4["predicted"] = pred
+            out["config4"] = config4
+        if config5 is not None:
+            out["config5"] = config5
         if host_image is not None:
             out["value_host_image"] = host_image
         if mixed is not None:
             out["value_mixed_precision"] = mixed
-        if frames_mode is not None:
-            out["value_whole_frames_per_gpu"] = frames_mode
         if native is not None:
             out["native_host"] = {"what": "the C++ host `course --bench` (one process, one c5_context per GPU) on the same grid, "
-                                          "view and image; frames delivered to pinned host memory; Mrays/s in mrays_per_s",
+                                          "view and image; frames delivered to pinned host memory (sweep_files: written as zlib "
+                                          ".vti files, end to end); Mrays/s in mrays_per_s",
                                   **native}
         if world == 1 and not args.no_cpu_baseline:
             sres = tuple(int(v) for v in args.cpu_sample_res.lower().split("x")) if args.cpu_sample_res else (res_x, res_y)

@@ -32,6 +32,18 @@ LIB_SOURCES = [
 ]
 
 
+def kernel_source_hash() -> str:
+    """sha256 over the device-side sources (csrc/*.hip, *.hpp), in name order: committed profiles carry the hash of
+    the sources they were measured on, and bench.py says when the sources have moved on since."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))):
+        h.update(name.encode())
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _newer(target: str, deps: list[str]) -> bool:
     if not os.path.exists(target):
         return True

@@ -262,20 +262,28 @@ class Context:
         rays = self.local_rows * self.res_x
         out = {}
         try:
-            for attempt in range(3):
-                redo = False
-                for k in range(ring):  # warm
-                    self.render_host_async(bufs[k])
-                for k in range(ring):
-                    redo |= self.render_host_wait() != C5_OK
-                t0 = time.perf_counter()
-                for k in range(frames):
+            def burst(n):
+                bad = False
+                for k in range(n):
                     if k >= ring:
-                        redo |= self.render_host_wait() != C5_OK
+                        bad |= self.render_host_wait() != C5_OK
                     self.render_host_async(bufs[k % ring])
-                for k in range(min(ring, frames)):
-                    redo |= self.render_host_wait() != C5_OK
+                for k in range(min(ring, n)):
+                    bad |= self.render_host_wait() != C5_OK
+                return bad
+
+            for attempt in range(3):
+                # warm: the ring's device images and pinned pages are touched, the copy stream exists, the clocks are up
+                # (BENCH_r02: 1.18 ms per frame over 20 cold frames against 0.78 sustained)
+                burst(max(40, ring))
+                t0 = time.perf_counter()
+                redo = burst(frames)
                 dt = time.perf_counter() - t0
+                if dt < 0.2 and not redo:  # at least 0.2 s of frames
+                    frames = int(frames * 0.25 / max(dt, 1e-3)) + 1
+                    t0 = time.perf_counter()
+                    redo = burst(frames)
+                    dt = time.perf_counter() - t0
                 if not redo:
                     break
             out["pipelined"] = {"ms_per_frame": round(dt * 1e3 / frames, 4), "value": round(rays * frames / dt / 1e6, 1),

@@ -381,12 +381,33 @@ void write_vti(const std::string& path, const float* image, int res_x, int res_y
         unsigned char* const scratch = scratch_buf.data();
         std::vector<uint64_t> packed_size(n_blocks, 0);
         const int64_t nb = static_cast<int64_t>(n_blocks);
+        // A full block of zeros (rays that meet nothing: most of a frame) deflates to the same bytes every time:
+        // deflated once, copied thereafter — deflate at level 1 runs at ~130 MB/s per core and is all a frame's
+        // write costs (measured: 570 ms on one core for a 2400x1800 frame, 135 ms on eight).
+        static const std::vector<unsigned char> zero_block = [&] {
+            std::vector<unsigned char> zeros(kBlock, 0), out(bound);
+            uLongf cap = bound;
+            if (compress2(out.data(), &cap, zeros.data(), static_cast<uLong>(kBlock), Z_BEST_SPEED) != Z_OK) cap = 0;
+            out.resize(cap);
+            return out;
+        }();
 #pragma omp parallel for schedule(dynamic, 16) num_threads(writer_threads())
         for (int64_t b = 0; b < nb; ++b) {
             const uint64_t first = static_cast<uint64_t>(b) * kBlock / sizeof(double);
             const uint64_t count = std::min<uint64_t>(kBlock / sizeof(double), n_values - first);
             double vals[kBlock / sizeof(double)];
-            for (uint64_t k = 0; k < count; ++k) vals[k] = static_cast<double>(image[first + k]);
+            uint32_t any = 0;  // +0.0f only (a -0.0f or a NaN has bits set)
+            for (uint64_t k = 0; k < count; ++k) {
+                uint32_t bits;
+                std::memcpy(&bits, image + first + k, sizeof bits);
+                any |= bits;
+                vals[k] = static_cast<double>(image[first + k]);
+            }
+            if (any == 0 && count == kBlock / sizeof(double) && !zero_block.empty()) {
+                std::memcpy(scratch + static_cast<size_t>(b) * bound, zero_block.data(), zero_block.size());
+                packed_size[static_cast<size_t>(b)] = zero_block.size();
+                continue;
+            }
             uLongf cap = bound;
             if (compress2(scratch + static_cast<size_t>(b) * bound, &cap, reinterpret_cast<const Bytef*>(vals),
                           static_cast<uLong>(count * sizeof(double)), Z_BEST_SPEED) != Z_OK)

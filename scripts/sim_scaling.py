@@ -1,55 +1,77 @@
-"""Scratch: estimate N-GPU strong scaling on ONE GPU by timing each rank's share of the frame
-in turn (no gather).  Prints per-rank GPU frame time for cyclic tiles and balanced blocks."""
-import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
-from course5_amd import capi, meshgen as mg, sharding
+"""What row-splitting a frame over N GPUs can give at best, measured on ONE GPU: every rank's share of the frame
+(cost-balanced contiguous blocks, and cyclic 16-row tiles) is rendered in turn and timed; the slowest share is the
+frame time of an N-GPU run without its exchange.  A ray is a chain of ~130 dependent steps, so a share's time does not
+fall in proportion to its rows.
 
-res = (2400, 1800) if len(sys.argv) < 2 else tuple(int(v) for v in sys.argv[1].split("x"))
-base = 0.5 if len(sys.argv) < 3 else float(sys.argv[2])
+    python scripts/sim_scaling.py [round-tag]      -> profiles/sim_scaling.json (read by bench.py: `predicted`)
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402,F401
+import torch  # noqa: E402,F401  (HIP runtime load order)
+from course5_amd import capi, meshgen as mg, sharding  # noqa: E402
+from course5_amd.build import kernel_source_hash  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+base = 6.0  # bench.py --row-base-cost
 ctx = capi.Context(0)
 xyz, c, a, q = mg.workload("c3")
 ctx.upload_grid(xyz, c, a, q)
-ctx.set_image(res[0], res[1], mg.REFERENCE_BOUNDS)
 ctx.set_view(mg.view_rotations(0.1, 0.07))
-ctx.set_option("row_costs", 1)
+out = {"round": tag, "source_hash": kernel_source_hash(), "workload": "c3, view -X 0.1 -Y 0.07, fp64 walk", "row_base_cost": base,
+       "what": "ms = GPU frame time (transform + records + entries + walk, HIP events) of the best of 8 renders after 30 warm ones",
+       "frames": {}}
+
 
 def timed():
+    for _ in range(30):
+        ctx.render()
     best = None
-    for _ in range(6):
+    for _ in range(8):
         ctx.render()
         st = ctx.stats()
         if best is None or st["ms_total"] < best["ms_total"]:
             best = st
     return best
 
-full = timed()
-costs = ctx.row_costs()
-print("full frame", {k: round(v, 3) for k, v in full.items() if k.startswith("ms_")})
-for world in (2, 4, 8):
-    blocks = sharding.balanced_blocks(costs, world, base_cost=res[0] * base)
-    per = []
-    for b, n in blocks:
-        ctx.set_row_range(b, n)
-        st = timed()
-        per.append(st)
-    ctx.set_row_range(0, -1)
-    tot = [round(p["ms_total"], 3) for p in per]
-    print(f"blocks world {world}: rows {[n for _, n in blocks]} ms_total {tot} max {max(tot)} -> speedup {full['ms_total'] / max(tot):.2f}",
-          "setup", [round(p["ms_transform"] + p["ms_records"] + p["ms_entries"], 3) for p in per],
-          "walk", [round(p["ms_walk"], 3) for p in per])
-    per = []
-    for r in range(world):
-        ctx.set_row_tiles(int(os.environ.get("TILE_ROWS", "16")), r, world)
-        per.append(timed())
+
+for res in ((2400, 1800), (4800, 3600)):
     ctx.set_row_tiles(0, 0, 1)
-    tot = [round(p["ms_total"], 3) for p in per]
-    print(f"cyclic world {world}: ms_total {tot} max {max(tot)} -> speedup {full['ms_total'] / max(tot):.2f}")
-# host-side enqueue cost of a frame
-import ctypes
-buf = np.zeros(1)
-ctx.set_option("stage_timing", 0)
-t = time.perf_counter()
-for _ in range(200):
-    ctx.lib.c5_render_device(ctx.handle, ctx.lib.c5_render_device.argtypes and ctypes.c_void_p(0) or None) if False else None
-print("done")
+    ctx.set_row_range(0, -1)
+    ctx.set_image(res[0], res[1], mg.REFERENCE_BOUNDS)
+    ctx.set_option("row_costs", 1)
+    full = timed()
+    costs = ctx.row_costs()
+    ctx.set_option("row_costs", 0)
+    full = timed()
+    entry = {"full_ms": round(full["ms_total"], 4), "full_walk_ms": round(full["ms_walk"], 4), "world": {}}
+    print(f"{res[0]}x{res[1]}: full frame {full['ms_total']:.3f} ms (walk {full['ms_walk']:.3f})", flush=True)
+    for world in (2, 4, 8):
+        blocks = sharding.balanced_blocks(costs, world, base_cost=res[0] * base)
+        per = []
+        for b, n in blocks:
+            ctx.set_row_range(b, n)
+            per.append(timed())
+        ctx.set_row_range(0, -1)
+        tot = [round(p["ms_total"], 4) for p in per]
+        e = {"blocks": {"rows": [n for _, n in blocks], "ms": tot, "max_ms": max(tot), "speedup": round(full["ms_total"] / max(tot), 3),
+                        "setup_ms": [round(p["ms_transform"] + p["ms_records"] + p["ms_entries"], 4) for p in per],
+                        "walk_ms": [round(p["ms_walk"], 4) for p in per]}}
+        per = []
+        for r in range(world):
+            ctx.set_row_tiles(16, r, world)
+            per.append(timed())
+        ctx.set_row_tiles(0, 0, 1)
+        tot = [round(p["ms_total"], 4) for p in per]
+        e["cyclic"] = {"ms": tot, "max_ms": max(tot), "speedup": round(full["ms_total"] / max(tot), 3)}
+        entry["world"][str(world)] = e
+        print(f"  N = {world}: blocks {e['blocks']['rows']} -> {e['blocks']['ms']} ms, x{e['blocks']['speedup']};  "
+              f"cyclic -> max {e['cyclic']['max_ms']} ms, x{e['cyclic']['speedup']}", flush=True)
+    out["frames"][f"{res[0]}x{res[1]}"] = entry
+with open(os.path.join(ROOT, "profiles", "sim_scaling.json"), "w") as f:
+    json.dump(out, f, indent=1)
+print("wrote profiles/sim_scaling.json")
