@@ -55,8 +55,9 @@ public:
         while (pos_ < buf_.size() && buf_[pos_] != '\n') ++pos_;
         if (pos_ < buf_.size()) ++pos_;
     }
+    size_t remaining() const { return buf_.size() - pos_; }
     const unsigned char* raw(size_t n) {
-        if (pos_ + n > buf_.size()) throw std::runtime_error("vtk: binary section runs past the end of the file");
+        if (n > buf_.size() - pos_) throw std::runtime_error("vtk: binary section runs past the end of the file");
         const unsigned char* p = reinterpret_cast<const unsigned char*>(buf_.data()) + pos_;
         pos_ += n;
         return p;
@@ -106,10 +107,15 @@ double binary_value(const std::string& t, const unsigned char* p) {
 // n values of `type` into doubles (ids up to 2^53 survive the trip)
 std::vector<double> read_array(cursor& c, bool binary, const std::string& type_in, size_t n) {
     const std::string type = lower(type_in);
+    // A count is a claim of the file: before anything of that size is allocated it must fit in what is left of the
+    // file (a binary value takes its size, an ASCII one a character and a separator at least) — a header that says
+    // "POINTS 999999999" on a 60 KB file is reported, not obeyed (24 GB of zeros first, found by the sanitizer run).
+    if (binary) c.rest_of_line();
+    const size_t sz = binary ? type_size(type) : 2;
+    if (n > (c.remaining() + 1) / sz)
+        throw std::runtime_error(binary ? "vtk: binary section runs past the end of the file" : "vtk: unexpected end of file (an array is shorter than its header says)");
     std::vector<double> out(n);
     if (binary) {
-        c.rest_of_line();
-        const size_t sz = type_size(type);
         const unsigned char* p = c.raw(n * sz);
         for (size_t i = 0; i < n; ++i) out[i] = binary_value(type, p + i * sz);
     } else {
@@ -126,7 +132,14 @@ std::vector<double> read_array(cursor& c, bool binary, const std::string& type_i
 size_t to_count(const std::string& t) {
     char* end = nullptr;
     const long long v = std::strtoll(t.c_str(), &end, 10);
-    if (end == t.c_str() || v < 0) throw std::runtime_error("vtk: expected a count, found '" + t + "'");
+    if (end == t.c_str() || *end != '\0' || v < 0 || v > (1ll << 31)) throw std::runtime_error("vtk: expected a count, found '" + t + "'");
+    return static_cast<size_t>(v);
+}
+
+// A point id or an offset as it came out of read_array (a double): a whole number below `limit`, or the file is wrong
+// (a float -> integer conversion out of range is undefined behaviour, not an error message).
+size_t to_index(double v, size_t limit, const char* what) {
+    if (!(v >= 0.0) || !(v < static_cast<double>(limit)) || v != std::floor(v)) throw std::runtime_error(std::string("vtk: ") + what);
     return static_cast<size_t>(v);
 }
 
@@ -180,20 +193,24 @@ vtk_grid read_legacy_vtk(const std::string& path) {
                 n_cells = a ? a - 1 : 0;
                 g.tets.resize(4 * n_cells);
                 for (size_t k = 0; k < n_cells; ++k) {
-                    const size_t lo = static_cast<size_t>(offsets[k]), hi = static_cast<size_t>(offsets[k + 1]);
-                    if (hi - lo < 4 || hi > conn.size()) throw std::runtime_error("vtk: a cell has fewer than four points");
-                    for (int v = 0; v < 4; ++v) g.tets[4 * k + v] = static_cast<int32_t>(conn[lo + v]);
+                    const size_t lo = to_index(offsets[k], conn.size() + 1, "a cell offset is out of range");
+                    const size_t hi = to_index(offsets[k + 1], conn.size() + 1, "a cell offset is out of range");
+                    if (hi < lo || hi - lo < 4) throw std::runtime_error("vtk: a cell has fewer than four points");
+                    for (int v = 0; v < 4; ++v)
+                        g.tets[4 * k + v] = static_cast<int32_t>(to_index(conn[lo + v], size_t{1} << 31, "cell references a point id out of range"));
                 }
             } else {  // classic: CELLS n size, then n records "k id0 ... id(k-1)"
                 n_cells = a;
                 const std::vector<double> raw = read_array(c, binary, "int", b);
+                if (n_cells > raw.size() / 5) throw std::runtime_error("vtk: CELLS section is truncated");  // 5 entries per tetrahedron at least
                 g.tets.resize(4 * n_cells);
                 size_t p = 0;
                 for (size_t k = 0; k < n_cells; ++k) {
                     if (p >= raw.size()) throw std::runtime_error("vtk: CELLS section is truncated");
-                    const size_t m = static_cast<size_t>(raw[p]);
+                    const size_t m = to_index(raw[p], raw.size(), "a cell's point count is out of range");
                     if (m < 4 || p + 1 + m > raw.size()) throw std::runtime_error("vtk: a cell has fewer than four points");
-                    for (int v = 0; v < 4; ++v) g.tets[4 * k + v] = static_cast<int32_t>(raw[p + 1 + v]);
+                    for (int v = 0; v < 4; ++v)
+                        g.tets[4 * k + v] = static_cast<int32_t>(to_index(raw[p + 1 + v], size_t{1} << 31, "cell references a point id out of range"));
                     p += 1 + m;
                 }
             }
@@ -229,6 +246,7 @@ vtk_grid read_legacy_vtk(const std::string& path) {
                 c.rest_of_line();
                 c.raw(4 * n);
             } else {
+                if (4 * n > c.remaining()) throw std::runtime_error("vtk: unexpected end of file");
                 for (size_t k = 0; k < 4 * n; ++k) c.token();
             }
         } else if (key == "vectors" || key == "normals") {

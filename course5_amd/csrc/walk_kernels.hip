@@ -480,18 +480,27 @@ __device__ __forceinline__ StepGeometry step_geometry_fast(const CellRegs& cur, 
     return g;
 }
 
-// Optional in-kernel phase clock (build with -DC5_WALK_STAMPS=1; scripts/stamp_walk.py): every wavefront
-// sums, per phase of a step, the shader cycles between stamps; lane 0 adds them to g_walk_stamps.
+// Optional in-kernel phase clock (build with -DC5_WALK_STAMPS=1; scripts/stamp_walk.py): ONE WAVEFRONT IN 64 sums, per
+// phase of a step, the shader cycles between stamps (s_memtime; tick = shader cycle) and lane 0 adds them to
+// g_walk_stamps; the other 63 run the product's instruction stream, so that the sampled wavefronts see the memory
+// system, the LDS and the issue ports as loaded as the product's do.  (Stamping every wavefront — the round-2 build —
+// made a step five times slower: 28 wavefronts per CU queueing for s_memtime five times per step, and 14 same-address
+// atomics per wavefront at the end of the launch.)
 #ifndef C5_WALK_STAMPS
 #define C5_WALK_STAMPS 0
 #endif
 #if C5_WALK_STAMPS
 __device__ unsigned long long g_walk_stamps[16];
-#define C5_STAMP(k)                                              \
-    do {                                                         \
-        const unsigned long long t_now_ = __builtin_amdgcn_s_memtime(); \
-        stamp_acc[k] += t_now_ - t_prev_;                        \
-        t_prev_ = t_now_;                                        \
+// launch timeline: per workgroup {start, end} in s_memrealtime ticks (100 MHz, one clock for the whole chip) and
+// {XCC_ID | HW_ID << 8, wavefront-steps}; zero = the workgroup had no ray (scripts/walk_timeline.py)
+__device__ unsigned long long g_walk_trace[4 * 131072];
+#define C5_STAMP(k)                                                      \
+    do {                                                                 \
+        if (stamping_) {                                                 \
+            const unsigned long long t_now_ = __builtin_amdgcn_s_memtime(); \
+            stamp_acc[k] += t_now_ - t_prev_;                            \
+            t_prev_ = t_now_;                                            \
+        }                                                                \
     } while (0)
 #else
 #define C5_STAMP(k) \
@@ -664,6 +673,8 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 6 : C5_DMA_WAVES) : C5_WAL
     // the wave-uniform iteration count IS the step count of every lane still walking: the guard
     // against malformed grids (never spin) is one scalar compare per iteration.
 #if C5_WALK_STAMPS
+    const bool stamping_ = (blockIdx.x & 63u) == 5u;  // wave-uniform
+    const unsigned long long trace_begin_ = __builtin_amdgcn_s_memrealtime();
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned stat_runs = 0, stat_distinct = 0, stat_iters = 0, stat_lanes = 0;
     unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
@@ -831,7 +842,7 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 6 : C5_DMA_WAVES) : C5_WAL
         }
         __builtin_amdgcn_wave_barrier();
 #if C5_WALK_STAMPS
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (stamping_) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         C5_STAMP(3);  // loads landed, pieces parked in LDS
 #endif
 
@@ -891,12 +902,22 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 6 : C5_DMA_WAVES) : C5_WAL
             nb = nxt;
         }
 #if C5_WALK_STAMPS
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (stamping_) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         C5_STAMP(4);  // record read back, geometry, exit face, (re-entry)
 #endif
     }
 #if C5_WALK_STAMPS
-    if (lane == 0) {
+    if (lane == 0 && blockIdx.x < 131072u) {
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned long long* t = g_walk_trace + 4ull * blockIdx.x;
+        t[0] = trace_begin_;
+        t[1] = __builtin_amdgcn_s_memrealtime();
+        t[2] = (static_cast<unsigned long long>(hw) << 8) | (xcc & 0xffu);
+        t[3] = stat_iters;
+    }
+    if (lane == 0 && stamping_) {
         for (int k = 0; k < 5; ++k) atomicAdd(&g_walk_stamps[k], stamp_acc[k]);
         atomicAdd(&g_walk_stamps[8], __builtin_amdgcn_s_memtime() - t_begin_);  // whole loop
         atomicAdd(&g_walk_stamps[9], 1ull);                                      // wavefronts
@@ -969,6 +990,16 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 6 : C5_DMA_WAVES) : C5_WAL
 }
 
 #if C5_WALK_STAMPS
+extern "C" int c5_debug_walk_trace(unsigned long long* out, int n_blocks, int reset) {
+    if (n_blocks > 131072) n_blocks = 131072;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walk_trace), 32ull * n_blocks) != hipSuccess) return 1;
+    if (reset) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_walk_trace)) != hipSuccess) return 1;
+        if (hipMemset(p, 0, sizeof(unsigned long long) * 4 * 131072) != hipSuccess) return 1;
+    }
+    return 0;
+}
 extern "C" int c5_debug_walk_stamps(unsigned long long* out16, int reset) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_walk_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
     if (reset) {

@@ -1,35 +1,47 @@
-"""Scratch: phase clock of walk_composite_lds (library built with -DC5_WALK_STAMPS=1, see walk_kernels.hip).
+"""In-kernel phase clock of walk_composite_lds (library built with -DC5_WALK_STAMPS=1, see walk_kernels.hip):
 
-    C5_LIB=course5_amd/libcourse5_hip_stamps.so python scripts/stamp_walk.py
+    scripts/build_variant.sh stamps -DC5_WALK_STAMPS=1
+    C5_LIB=course5_amd/libcourse5_hip_stamps.so python scripts/stamp_walk.py [round-tag]   -> profiles/<tag>_walk_phases.md
+
+One wavefront in 64 sums, per phase of a step, the s_memtime ticks (= shader cycles, MI355X_MICROARCH.md) between
+stamps; it drains vmcnt / lgkmcnt at the two stamps that end a phase of waiting, so its split is exact; the other 63
+run the product's instruction stream, so the sampled wavefronts see the machine as loaded as the product does.
 """
-import ctypes as C, os, sys
-import torch
+import ctypes as C
+import json
+import os
+import sys
+
+import torch  # noqa: F401
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from course5_amd import capi, meshgen as mg
+from course5_amd import capi, meshgen as mg  # noqa: E402
+from course5_amd.build import kernel_source_hash  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ctx = capi.Context(0)
 xyz, c, a, q = mg.workload("c3")
 ctx.upload_grid(xyz, c, a, q)
 ctx.set_image(2400, 1800, mg.REFERENCE_BOUNDS)
 ctx.set_view(mg.view_rotations(0.1, 0.07))
 lib = capi.load_library()
+if not hasattr(lib, "c5_debug_walk_stamps"):
+    raise SystemExit("this library was not built with -DC5_WALK_STAMPS=1 (scripts/build_variant.sh stamps -DC5_WALK_STAMPS=1)")
 out = torch.zeros((1800, 2400, 2), dtype=torch.float32, device="cuda:0")
 buf = (C.c_ulonglong * 16)()
-for i in range(3):
-    ctx.render()
-lib.c5_debug_walk_stamps(buf, 1)
-for tile in (0, 1, 2):
-    ctx.set_option("tile", tile)
-    ctx.render()
-    ctx.render()
-    lib.c5_debug_walk_stamps(buf, 1)
-    ctx.render()
-    lib.c5_debug_walk_stamps(buf, 1)
-    w = list(buf)
-    it = max(w[12], 1)
-    print(f"tile {tile}: iterations {w[12]}  walking lanes/iter {w[13] / it:.1f}  runs/iter {w[10] / it:.1f}  distinct cells/iter {w[11] / it:.1f}")
-names = ["election (lanes -> slots)", "ids read + staging loads issued", "emission step (exp)", "loads landed (+ ds_write)", "ds_read + geometry + exit"]
-for stage in (1, 2):
-    ctx.set_option("tile", 2)
+names = ["election: ticket -> leader -> slot (2 LDS round trips)",
+         "slot ids read back + staging loads (LDS-DMA) issued",
+         "emission / absorption of the previous step (exp), in the loads' shadow",
+         "staging loads land: s_waitcnt vmcnt(0)",
+         "10 x ds_read_b128 + four planes + exit face (+ re-entry)"]
+short = ["election", "issue", "emission", "load wait", "read + geometry"]
+lines = [f"# {tag}: phase clock of walk_composite_lds<3, 0, true, 16> on the C3 frame (2400x1800, fp64 walk)", "",
+         "`scripts/build_variant.sh stamps -DC5_WALK_STAMPS=1 && C5_LIB=course5_amd/libcourse5_hip_stamps.so python scripts/stamp_walk.py`",
+         f"kernel sources: {kernel_source_hash()}", ""]
+result = {}
+for stage, label in ((2, "LDS-DMA staging (default)"), (1, "staged through vector registers")):
+    ctx.set_option("tile", 3)
     ctx.set_option("lds_stage", stage)
     for _ in range(300):  # sustained clocks (the first frames after an idle spell run slower)
         ctx.render_device(out.data_ptr())
@@ -40,7 +52,23 @@ for stage in (1, 2):
     lib.c5_debug_walk_stamps(buf, 1)
     v = list(buf)
     tot = sum(v[:5])
-    print("lds_stage", stage, "walk ms", st["ms_walk"], "lane-steps", st["steps"], "wavefronts", v[9], "loop ticks/wave", v[8] / max(v[9], 1),
-          "ticks per wave-step", tot / max(v[12], 1))
+    steps = max(v[12], 1)
+    lines += [f"## lds_stage {stage}: {label}", "",
+              f"walk {st['ms_walk']:.3f} ms (stamped build: one wavefront in 64 stamps), {st['steps']} lane-steps in the frame; sampled: "
+              f"{v[9]} wavefronts with rays, {v[12]} wavefront-steps ({v[13] / steps:.1f} walking lanes per step), loop "
+              f"{v[8] / max(v[9], 1):.0f} cycles per wavefront, **{tot / steps:.0f} shader cycles per wavefront-step**", "",
+              "| phase | cycles | share | cycles per wavefront-step |", "|---|---|---|---|"]
     for n, x in zip(names, v[:5]):
-        print(f"  {n:34s} {x:14d} ticks  {100.0 * x / tot:5.1f} %   {x / max(v[12], 1):7.2f} per wave-step")
+        lines.append(f"| {n} | {x} | {100.0 * x / tot:.1f} % | {x / steps:.2f} |")
+    lines.append("")
+    if stage == 2:
+        k = max(range(5), key=lambda i: v[i])
+        result = {"cycles_per_wave_step": round(tot / steps, 1), "cycles": {short[i]: round(v[i] / steps, 1) for i in range(5)},
+                  "share": {short[i]: round(v[i] / tot, 4) for i in range(5)}, "dominant": short[k],
+                  "walking_lanes_per_step": round(v[13] / steps, 2), "source": f"profiles/{tag}_walk_phases.md"}
+text = "\n".join(lines) + "\n"
+print(text)
+with open(os.path.join(ROOT, "profiles", f"{tag}_walk_phases.md"), "w") as f:
+    f.write(text)
+with open(os.path.join(ROOT, "profiles", f"{tag}_walk_phases.json"), "w") as f:
+    json.dump(result, f, indent=1)

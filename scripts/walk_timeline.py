@@ -1,0 +1,74 @@
+"""Launch timeline of walk_composite_lds on the C3 frame (library built with -DC5_WALK_STAMPS=1): when every wavefront
+with rays started and ended (s_memrealtime, 100 MHz), on which XCD; from it the wavefront slots in use over the launch,
+per-XCD finish times and how much of the launch is ramp and tail.
+
+    scripts/build_variant.sh stamps -DC5_WALK_STAMPS=1
+    C5_LIB=course5_amd/libcourse5_hip_stamps.so python scripts/walk_timeline.py [round-tag]  -> profiles/<tag>_walk_timeline.md
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch  # noqa: F401
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from course5_amd import capi, meshgen as mg  # noqa: E402
+from course5_amd.build import kernel_source_hash  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+opts = dict(kv.split("=") for kv in os.environ.get("C5_OPTS", "").split(",") if kv)
+ctx = capi.Context(0)
+xyz, c, a, q = mg.workload("c3")
+ctx.upload_grid(xyz, c, a, q)
+res = tuple(int(v) for v in os.environ.get("C5_RES", "2400x1800").split("x"))
+ctx.set_image(res[0], res[1], mg.REFERENCE_BOUNDS)
+ctx.set_view(mg.view_rotations(0.1, 0.07))
+for k, v in opts.items():
+    ctx.set_option(k, float(v))
+lib = capi.load_library()
+n_blocks = 131072
+buf = (C.c_ulonglong * (4 * n_blocks))()
+out = torch.zeros((res[1], res[0], 2), dtype=torch.float32, device="cuda:0")
+for _ in range(300):
+    ctx.render_device(out.data_ptr())
+ctx.synchronize()
+lib.c5_debug_walk_trace(buf, n_blocks, 1)
+ctx.set_option("stage_timing", 1)
+ctx.render()
+st = ctx.stats()
+lib.c5_debug_walk_trace(buf, n_blocks, 1)
+t = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4)
+t = t[t[:, 1] > 0]
+b, e = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)
+xcc = (t[:, 2] & 0xff).astype(int)
+steps = t[:, 3].astype(np.int64)
+t0 = b.min()
+b, e = (b - t0) / 100.0, (e - t0) / 100.0  # microseconds
+span = e.max()
+lines = [f"# {tag}: launch timeline of the walk on the C3 frame ({res[0]}x{res[1]}), options {opts or 'default'}", "",
+         f"kernel sources {kernel_source_hash()}; walk {st['ms_walk']:.3f} ms by HIP events; {len(t)} wavefronts with rays, first start to last end {span:.1f} us; "
+         f"wavefront lifetime: median {np.median(e - b):.1f} us, 90 % {np.percentile(e - b, 90):.1f}, max {(e - b).max():.1f}; "
+         f"steps per wavefront: median {np.median(steps):.0f}, max {steps.max()}; {np.median((e - b) * 1e3 / np.maximum(steps, 1)):.0f} ns per wavefront-step", ""]
+# slots in use over time
+grid = np.linspace(0, span, 41)
+lines += ["| time (us) | wavefronts with rays resident | of 7168 slots |", "|---|---|---|"]
+for x in grid[:-1] + (grid[1] - grid[0]) / 2:
+    n = int(((b <= x) & (e > x)).sum())
+    lines.append(f"| {x:.0f} | {n} | {n / 7168:.2f} |")
+busy = (e - b).sum()
+lines += ["", f"slot-time used by wavefronts with rays: {busy:.0f} us = {busy / (7168 * span):.3f} of 7168 slots x {span:.1f} us", ""]
+lines += ["| XCD | wavefronts | wavefront-steps | first start (us) | last end (us) | slot-time (us) |", "|---|---|---|---|---|---|"]
+for x in sorted(set(xcc)):
+    m = xcc == x
+    lines.append(f"| {x} | {int(m.sum())} | {int(steps[m].sum())} | {b[m].min():.1f} | {e[m].max():.1f} | {(e[m] - b[m]).sum():.0f} |")
+# tail: when does the number of resident wavefronts fall below half the slots for good
+order = np.sort(e)
+lines += ["", f"ends: 50 % of the wavefronts have ended by {order[len(order) // 2]:.1f} us, 90 % by {order[int(len(order) * 0.9)]:.1f}, "
+              f"99 % by {order[int(len(order) * 0.99)]:.1f}, all by {span:.1f}",
+          f"starts: last wavefront with rays starts at {b.max():.1f} us"]
+text = "\n".join(lines) + "\n"
+print(text)
+with open(os.path.join(ROOT, "profiles", f"{tag}_walk_timeline.md"), "w") as f:
+    f.write(text)

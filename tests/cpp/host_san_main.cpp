@@ -1,0 +1,137 @@
+// Sanitizer harness for the CPU side: the host-only translation units of the product
+// (csrc/host/vtk_io.cpp, cli.cpp, scene.cpp; csrc/adjacency.cpp) and the oracle (oracle/oracle.cpp) built with
+// -fsanitize=address,undefined into ONE program with no HIP runtime and no GPU.  tests/test_sanitizers_cpu.py builds it
+// and drives it with well-formed and malformed inputs: every run must end in a result or an error MESSAGE, never in
+// a sanitizer report.
+//
+//   host_san read   <file.vtk>              parse (tokenizer, big-endian, 5.1 layout), weld, adjacency -> counts
+//   host_san vti    <out.vti> <w> <h> <raw> write a synthetic frame (zero blocks, NaNs, ragged last block) + PNG
+//   host_san cli    <args...>               the option parser on the given command line
+//   host_san solids                         init_polar: Roche lobe + sphere, unique faces -> counts
+//   host_san oracle <scene.bin> <out.f32>   the CPU oracle on a dumped scene (see the pytest for the layout)
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "adjacency.hpp"
+#include "cli.hpp"
+#include "config.hpp"
+#include "scene.hpp"
+#include "vtk_io.hpp"
+
+extern "C" int c5o_render(const double* xyz, int64_t n_pts, const int32_t* cell_vert, int64_t n_cells, const double* alpha,
+                          const double* q, const double* rots, int n_rot, const double* solid_tets, const double* solid_colour,
+                          int64_t n_solid, int res_x, int res_y, const double* bounds4, double alpha_limit, int threads, float* out,
+                          int64_t* stats, double* timing_ms, const int32_t* probe_ij, int n_probe, int probe_cap, double* probe_out,
+                          int32_t* probe_count, char* err, int errlen);
+
+namespace {
+template <class T>
+std::vector<T> take(std::ifstream& f, size_t n) {
+    std::vector<T> v(n);
+    f.read(reinterpret_cast<char*>(v.data()), static_cast<std::streamsize>(n * sizeof(T)));
+    if (!f) throw std::runtime_error("scene file too short");
+    return v;
+}
+}  // namespace
+
+int main(int argc, char** argv) try {
+    if (argc < 2) throw std::runtime_error("usage: host_san read|vti|cli|solids|oracle ...");
+    const std::string mode = argv[1];
+    if (mode == "read") {
+        if (argc < 3) throw std::runtime_error("read: file?");
+        const vtk_grid g = read_legacy_vtk(argv[2]);
+        std::vector<int32_t> rep, adj;
+        std::vector<uint32_t> bfaces;
+        std::string err;
+        const int64_t merged = c5::weld_points(g.points.data(), g.n_points(), rep);
+        std::vector<int32_t> cells(g.tets);
+        for (int32_t& id : cells) {
+            if (id < 0 || id >= g.n_points()) throw std::runtime_error("cell references a point id out of range");
+            id = rep[static_cast<size_t>(id)];
+        }
+        const bool ok = c5::build_face_adjacency(cells.data(), g.n_cells(), g.n_points(), adj, bfaces, err);
+        std::printf("points %lld cells %lld scalars %zu merged %lld conforming %d boundary_faces %zu%s%s\n",
+                    static_cast<long long>(g.n_points()), static_cast<long long>(g.n_cells()), g.cell_scalars.size(),
+                    static_cast<long long>(merged), ok ? 1 : 0, bfaces.size(), ok ? "" : " : ", ok ? "" : err.c_str());
+        // the same through the scene object the CLI builds (object3d_base::read_vtk_file)
+        object3d_accretion_disk disk{std::string(argv[2])};
+        std::printf("disk cells %zu\n", disk.get_pointer()->size());
+        return 0;
+    }
+    if (mode == "vti") {
+        if (argc < 6) throw std::runtime_error("vti: out w h raw?");
+        const int w = std::atoi(argv[3]), h = std::atoi(argv[4]);
+        const bool raw = std::atoi(argv[5]) != 0;
+        std::vector<float> px(static_cast<size_t>(w) * h * 2, 0.0f);
+        for (int y = h / 3; y < 2 * h / 3; ++y)  // a band of values between bands of zeros (whole zero blocks either side)
+            for (int x = w / 4; x < 3 * w / 4; ++x) {
+                px[(static_cast<size_t>(y) * w + x) * 2] = static_cast<float>(x) * 0.25f + static_cast<float>(y);
+                px[(static_cast<size_t>(y) * w + x) * 2 + 1] = std::sin(static_cast<float>(x * y));
+            }
+        px[0] = -0.0f;  // not a zero block: -0.0 has a bit set
+        px[px.size() - 1] = std::numeric_limits<float>::quiet_NaN();
+        write_vti(argv[2], px.data(), w, h, !raw);
+        double lo = 0, hi = 0;
+        colour_range(px.data(), w, h, 1, &lo, &hi);
+        write_png(std::string(argv[2]) + ".png", px.data(), w, h, 1, lo, hi);
+        std::printf("wrote %dx%d range %g %g\n", w, h, lo, hi);
+        return 0;
+    }
+    if (mode == "cli") {
+        const bool go = program_options(argc - 1, argv + 1, std::cout);
+        const render_config& c = app::instance().config;
+        std::printf("go %d file '%s' res %zux%zu frames %zu devices '%s' layout %s\n", go ? 1 : 0, c.file.c_str(), c.resolution_x,
+                    c.resolution_y, c.frames, c.devices.c_str(), c.row_layout.c_str());
+        return 0;
+    }
+    if (mode == "solids") {
+        object3d_roche_lobe lobe(point{ACC_X0, ACC_Y0, ACC_Z0}, L, 0.3 * PI, M_ACC, M_DONOR, OMEGA);
+        object3d_sphere sphere(point{ACC_X0, ACC_Y0, ACC_Z0}, ACC_DISK_R);
+        for (object3d_base* o : {static_cast<object3d_base*>(&lobe), static_cast<object3d_base*>(&sphere)}) {
+            const object3d_data& d = *o->get_pointer();
+            std::vector<double> pts;
+            std::vector<int32_t> faces;
+            c5::unique_solid_faces(d.soup.data(), static_cast<int64_t>(d.soup.size() / 12), pts, faces);
+            std::printf("solid cells %zu unique points %zu unique faces %zu\n", d.size(), pts.size() / 3, faces.size() / 4);
+        }
+        return 0;
+    }
+    if (mode == "oracle") {
+        if (argc < 4) throw std::runtime_error("oracle: scene out?");
+        std::ifstream f(argv[2], std::ios::binary);
+        if (!f) throw std::runtime_error("cannot open scene");
+        const std::vector<int64_t> hd = take<int64_t>(f, 6);  // n_pts, n_cells, n_rot, res_x, res_y, n_solid
+        const std::vector<double> xyz = take<double>(f, static_cast<size_t>(3 * hd[0]));
+        const std::vector<int32_t> cells = take<int32_t>(f, static_cast<size_t>(4 * hd[1]));
+        const std::vector<double> alpha = take<double>(f, static_cast<size_t>(hd[1])), q = take<double>(f, static_cast<size_t>(hd[1]));
+        const std::vector<double> rots = take<double>(f, static_cast<size_t>(3 * hd[2]));
+        const std::vector<double> bounds = take<double>(f, 4), limit = take<double>(f, 1);
+        const std::vector<double> solids = take<double>(f, static_cast<size_t>(12 * hd[5])), colour = take<double>(f, static_cast<size_t>(hd[5]));
+        std::vector<float> out(static_cast<size_t>(hd[3] * hd[4] * 2));
+        int64_t stats[4] = {0, 0, 0, 0};
+        double timing[3];
+        char err[512] = {0};
+        const int rc = c5o_render(xyz.data(), hd[0], cells.data(), hd[1], alpha.data(), q.data(), rots.data(), static_cast<int>(hd[2]),
+                                  hd[5] ? solids.data() : nullptr, hd[5] ? colour.data() : nullptr, hd[5], static_cast<int>(hd[3]),
+                                  static_cast<int>(hd[4]), bounds.data(), limit[0], 2, out.data(), stats, timing, nullptr, 0, 0, nullptr,
+                                  nullptr, err, sizeof err);
+        if (rc != 0) throw std::runtime_error(std::string("oracle: ") + err);
+        std::ofstream o(argv[3], std::ios::binary);
+        o.write(reinterpret_cast<const char*>(out.data()), static_cast<std::streamsize>(out.size() * sizeof(float)));
+        std::printf("segments %lld covered %lld marked %lld\n", static_cast<long long>(stats[0]), static_cast<long long>(stats[1]),
+                    static_cast<long long>(stats[2]));
+        return 0;
+    }
+    throw std::runtime_error("unknown mode '" + mode + "'");
+} catch (const std::exception& e) {
+    std::fprintf(stderr, "host_san: %s\n", e.what());
+    return 1;
+}
