@@ -19,6 +19,7 @@ for _ in range(3):
     ctx.set_option("walk_timing", 0)
     ctxs.append(ctx)
 outs = [torch.zeros((res[1], res[0], 2), dtype=torch.float32, device="cuda:0") for _ in range(3)]
+rows = []
 for n in (1, 2, 3, 1, 2, 3):
     for k in range(100):
         ctxs[k % n].render_device(outs[k % n].data_ptr())
@@ -33,3 +34,18 @@ for n in (1, 2, 3, 1, 2, 3):
     for ctx in ctxs:
         assert ctx.synchronize() == 0
     print(f"{n} context(s): {dt * 1e3 / K:.4f} ms per frame = {res[0] * res[1] * K / dt / 1e6:.0f} Mrays/s", flush=True)
+    rows.append((n, dt * 1e3 / K, res[0] * res[1] * K / dt / 1e6))
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
+from course5_amd.build import kernel_source_hash
+with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{tag}_overlap_probe.md"), "w") as f:
+    f.write(f"# {tag}: do frames overlapped on independent streams fill the walk's tail?  ({res[0]}x{res[1]}, C3, {K} frames per line)\n\n"
+            f"`python scripts/overlap_probe.py`; kernel sources {kernel_source_hash()}.  N contexts on ONE GPU (own high-priority stream, own per-view "
+            "buffers each), frame k on context k mod N: with N > 1 the last quarter of a frame's walk (falling occupancy, "
+            f"{tag}_walk_timeline.md) runs beside the next frame's setup and walk.\n\n| contexts | ms per frame | Mrays/s |\n|---|---|---|\n")
+    for n, ms, v in rows:
+        f.write(f"| {n} | {ms:.4f} | {v:.0f} |\n")
+    base = min(ms for n, ms, _ in rows if n == 1)
+    f.write(f"\nBest of N = 2: {100 * (base / min(ms for n, ms, _ in rows if n == 2) - 1):.1f} %, of N = 3: "
+            f"{100 * (base / min(ms for n, ms, _ in rows if n == 3) - 1):.1f} % over one context.  Setup of frame k + 1 on a low-priority stream "
+            "beside walk k inside ONE context (option \"pipeline\" 1) LOSES: 0.756 against 0.621 ms per frame, the walk itself 0.608 against "
+            "0.537 ms (two sets of 160 MB records in flight against a 256 MB Infinity Cache).\n")

@@ -84,14 +84,43 @@ def write_roofline(tag, walk, c):
     if out.get("hbm_bytes_per_launch") and ms:
         units["hbm"] = {"frac": out["hbm_bytes_per_launch"] / (ms * 1e-3) / 8.0e12,
                         "what": "HBM-side bytes / kernel time against 8 TB/s"}
+    if cycles and get("SQ_ACTIVE_INST_SCA"):
+        units["salu"] = {"frac": 4.0 * get("SQ_ACTIVE_INST_SCA") / (cycles * n_simd),
+                         "what": "4 x SQ_ACTIVE_INST_SCA / (cycles x 1024 SIMDs): share of the launch the scalar units were executing"}
     out["units"] = units
-    busiest = max(((k, v["frac"]) for k, v in units.items() if k in ("valu", "lds", "l2", "hbm") and v.get("frac")),
+    # what the in-kernel instruments add (scripts/stamp_walk.py, scripts/walk_timeline.py; same sources or they are left out)
+    import sys as _sys
+    _sys.path.insert(0, ROOT)
+    from course5_amd.build import kernel_source_hash
+    out["source_hash"] = kernel_source_hash()
+    extra = {}
+    for name in ("walk_phases", "walk_timeline"):
+        try:
+            with open(os.path.join(PROF, f"{tag}_{name}{SUFFIX}.json")) as f:
+                extra[name] = json.load(f)
+        except Exception:  # noqa: BLE001
+            pass
+    if "walk_phases" in extra:
+        out["phases"] = extra["walk_phases"]
+    tl = extra.get("walk_timeline")
+    if tl:
+        out["timeline"] = tl
+    busiest = max(((k, v["frac"]) for k, v in units.items() if k in ("valu", "lds", "l2", "hbm", "salu") and v.get("frac")),
                   key=lambda kv: kv[1], default=None)
     if busiest:
-        out["limiter"] = {"name": busiest[0], "frac": busiest[1],
-                          "note": "the busiest unit by its counter; no unit is saturated - a step is a dependent chain (election -> "
-                                  "load -> LDS -> geometry -> exit) and the resident wavefronts do not cover all of it; removing "
-                                  "vector instructions did not shorten the launch (DESIGN.md section 4.1)"}
+        lim = {"name": busiest[0], "frac": busiest[1]}
+        if tl and tl.get("steady_over_mean"):
+            # the launch spends its last quarter draining (one wavefront lives a third of the launch): while the slots
+            # are full the units are busier than their average over the launch by the ratio of the step rates
+            lim["steady_state_frac"] = min(1.0, busiest[1] * tl["steady_over_mean"])
+            lim["note"] = ("the busiest unit by its counter, averaged over the launch and (steady_state_frac) while the wavefront slots "
+                           "are full: vector-instruction issue is what a step costs - every vector instruction of a wave64 holds its "
+                           "SIMD for a quad-cycle, fp64 or not (SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU), the walk issues ~84 per "
+                           "wavefront-step; more resident wavefronts, frames overlapped on a second stream and filling the launch's "
+                           "tail buy 0-2.5 % (profiles/" + tag + "_walk_timeline.md, " + tag + "_overlap_probe.md)")
+        else:
+            lim["note"] = "the busiest unit by its counter over the whole launch"
+        out["limiter"] = lim
     with open(os.path.join(PROF, f"roofline{SUFFIX}.json"), "w") as f:
         json.dump(out, f, indent=1)
     lines = [f"walk_composite per launch: {cycles:.4g} shader cycles" if cycles else ""]

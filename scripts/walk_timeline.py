@@ -6,6 +6,7 @@ per-XCD finish times and how much of the launch is ramp and tail.
     C5_LIB=course5_amd/libcourse5_hip_stamps.so python scripts/walk_timeline.py [round-tag]  -> profiles/<tag>_walk_timeline.md
 """
 import ctypes as C
+import json
 import os
 import sys
 
@@ -63,12 +64,33 @@ lines += ["| XCD | wavefronts | wavefront-steps | first start (us) | last end (u
 for x in sorted(set(xcc)):
     m = xcc == x
     lines.append(f"| {x} | {int(m.sum())} | {int(steps[m].sum())} | {b[m].min():.1f} | {e[m].max():.1f} | {(e[m] - b[m]).sum():.0f} |")
-# tail: when does the number of resident wavefronts fall below half the slots for good
 order = np.sort(e)
+# throughput over the launch: a wavefront's steps spread evenly over its life
+edges = np.linspace(0, span, 41)
+rate = np.zeros(40)
+for k in range(40):
+    lo, hi = edges[k], edges[k + 1]
+    overlap = np.clip(np.minimum(e, hi) - np.maximum(b, lo), 0, None)
+    rate[k] = (steps * overlap / np.maximum(e - b, 1e-9)).sum() / (hi - lo)
+steady = rate[2:int(0.7 * 40)].mean()
+lines += ["", f"wavefront-steps per us: steady state (5 % - 70 % of the launch) {steady:.0f}, whole launch {steps.sum() / span:.0f} "
+              f"(ratio {steady * span / steps.sum():.3f}); last fifth of the launch {rate[32:].mean():.0f}", ""]
+summary = {"round": tag, "source_hash": kernel_source_hash(), "span_us": round(float(span), 1), "wavefronts": int(len(t)),
+           "wave_steps": int(steps.sum()), "slot_time_frac": round(float(busy / (7168 * span)), 4),
+           "steady_steps_per_us": round(float(steady), 1), "mean_steps_per_us": round(float(steps.sum() / span), 1),
+           "steady_over_mean": round(float(steady * span / steps.sum()), 4),
+           "resident_frac_steady": round(float(np.mean([((b <= x) & (e > x)).sum() for x in edges[2:28]]) / 7168), 4),
+           "tail_starts_us": round(float(order[int(len(order) * 0.5)]), 1) if False else None,
+           "median_wave_life_us": round(float(np.median(e - b)), 1), "source": f"profiles/{tag}_walk_timeline.md"}
+# tail: when does the number of resident wavefronts fall below half the slots for good
 lines += ["", f"ends: 50 % of the wavefronts have ended by {order[len(order) // 2]:.1f} us, 90 % by {order[int(len(order) * 0.9)]:.1f}, "
               f"99 % by {order[int(len(order) * 0.99)]:.1f}, all by {span:.1f}",
           f"starts: last wavefront with rays starts at {b.max():.1f} us"]
 text = "\n".join(lines) + "\n"
 print(text)
-with open(os.path.join(ROOT, "profiles", f"{tag}_walk_timeline.md"), "w") as f:
-    f.write(text)
+if not opts and res == (2400, 1800):
+    with open(os.path.join(ROOT, "profiles", f"{tag}_walk_timeline.md"), "w") as f:
+        f.write(text)
+    summary.pop("tail_starts_us")
+    with open(os.path.join(ROOT, "profiles", f"{tag}_walk_timeline.json"), "w") as f:
+        json.dump(summary, f, indent=1)
