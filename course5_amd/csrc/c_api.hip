@@ -532,7 +532,8 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     const bool fused = !mixed && ctx->fuse_setup && !side && g.n_cells > 0;
     if (!fused) C5_HIP(ctx, mark(2, s));
     // boundary entries: one raster pass (per-pixel count + first entry + overflow chain)
-    const double key_floor = !ctx->entry_key ? -1.0 : (mixed ? c5::kEntryKeyFloorMixed : c5::kEntryKeyFloor);
+    const double domain = std::fabs(ctx->bounds[0] - ctx->bounds[1]) + std::fabs(ctx->bounds[2] - ctx->bounds[3]);
+    const double key_slack = !ctx->entry_key ? -1.0 : (mixed ? c5::kEntryKeySlackMixed : c5::kEntryKeySlack) * domain;
     if (!fs.head_clean) C5_HIP(ctx, hipMemsetAsync(fs.head.ptr, 0, static_cast<size_t>(padded) * sizeof(c5::EntryHead), e));
     fs.head_clean = false;
     if (fused) {
@@ -540,7 +541,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
         // time of both and ms_entries is zero)
         c5::launch_setup_fused(s, g, ctx->alpha_limit, ctx->order, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im,
                                fs.head.as<c5::EntryHead>(), fs.first.as<c5::Entry>(), fs.pool.as<c5::Entry>(), fs.entry_capacity,
-                               fs.counters.as<c5::FrameCounters>(), ctx->sticky.as<unsigned>(), ctx->order != 0, key_floor);
+                               fs.counters.as<c5::FrameCounters>(), ctx->sticky.as<unsigned>(), ctx->order != 0, key_slack);
         // (the fused launch rewrites every cell's optics for the current limit and order)
         fs.optics_valid = true;
         fs.optics_limit = ctx->alpha_limit;
@@ -550,7 +551,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
         c5::launch_entry_lists(e, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im, fs.head.as<c5::EntryHead>(),
                                fs.first.as<c5::Entry>(), fs.pool.as<c5::Entry>(), fs.entry_capacity,
                                fs.counters.as<c5::FrameCounters>(), ctx->sticky.as<unsigned>(), ctx->order != 0,
-                               key_floor);
+                               key_slack);
     }
     C5_HIP(ctx, mark(3, e));
     // (a9) solids

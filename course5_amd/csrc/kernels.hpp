@@ -95,19 +95,19 @@ size_t segment_bytes();
 void launch_mask_overlay(hipStream_t s, const uint32_t* src, uint32_t* dst, int64_t n_padded);
 
 // walk_kernels.hip
-// key_floor of the two launchers below: how far (relative to a boundary face's extent, at least) an entry's depth key
-// lies behind its face (walk_common.hpp: entry_key_slack)
-constexpr double kEntryKeyFloor = 0x1p-18;       // fp64 walk
-constexpr double kEntryKeyFloorMixed = 0x1p-12;  // "precision" 1: exit depths carry fp32 rounding
+// key_slack of the two launchers below: how far an entry's depth key lies behind its face (walk_common.hpp:
+// entry_key_slack) = this fraction of the image domain's extent (x range + y range), the same for every face
+constexpr double kEntryKeySlack = 0x1p-24;       // fp64 walk
+constexpr double kEntryKeySlackMixed = 0x1p-13;  // "precision" 1: exit depths carry fp32 rounding
 // with_optics: also rebuild the cells' optics (view-independent: only when scalars, alpha limit or order changed)
 void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, int order, bool with_optics);
 void launch_entry_lists(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
                         const ImageParams& im, EntryHead* head, Entry* first, Entry* pool, int64_t capacity,
-                        FrameCounters* counters, unsigned* sticky, int want_upper, double key_floor);
+                        FrameCounters* counters, unsigned* sticky, int want_upper, double key_slack);
 // build_records and entry_raster as one launch of interleaved workgroups
 void launch_setup_fused(hipStream_t s, const GridView& g, double alpha_limit, int order, const double* Xtab, const double* Ytab,
                         const ImageParams& im, EntryHead* head, Entry* first, Entry* pool, int64_t capacity,
-                        FrameCounters* counters, unsigned* sticky, int want_upper, double key_floor);
+                        FrameCounters* counters, unsigned* sticky, int want_upper, double key_slack);
 void launch_walk(hipStream_t s, const WalkParams& p, int tile_shape);
 
 // walk_mixed.hip ("precision" 1)

@@ -274,8 +274,8 @@ __device__ __forceinline__ EntryHead load_entry_head(const EntryHead* p) {
 // next place the ray enters the grid beyond s_cur (s = z walking down, -z walking up); -1 if none.
 // The pixel's entries are first[lp] and the chain through the overflow pool (entry_raster).
 //
-// An entry's `z` is a depth KEY, not the entry face's depth: entry_raster pushes it a tolerance (entry_key_slack,
-// below) along the walk, INTO the cell the face belongs to.  Where two cells meet at faces that do not match
+// An entry's `z` is a depth KEY, not the entry face's depth: entry_raster pushes it a slack (entry_key_slack, below; the
+// same for every face of the frame) along the walk, INTO the cell the face belongs to.  Where two cells meet at faces that do not match
 // (hanging nodes: a coarse face against several fine ones — conforming in space, not in connectivity; the
 // reference never looks at connectivity, object3d_base.cpp:37-42 + plane.cpp:184-192 + line.cpp:138) both faces
 // are boundary faces, the ray leaves through one and has to enter through the other AT THE SAME DEPTH — the same
@@ -318,20 +318,28 @@ __device__ __forceinline__ int next_entry(const WalkParams& P, size_t lp, EntryH
 // (count -> scan -> fill took 35 + 30 + 52 us on the C3 frame); first[] is never cleared, only the
 // 8-byte heads are.
 // ------------------------------------------------------------------------------------------
-// How far an entry's depth key lies behind its face (see next_entry).  Too small loses the rest of a ray at a
-// non-matching interface; too large can only skip a stretch of grid THINNER than the slack that is followed by
-// another entry within the slack (both orders of two such keys are then possible) — a loss bounded by the
-// slack itself.  So it is generous: at least `floor_rel` of the face's extent (2^-18: 4e-6 of a cell; the
-// mixed-precision walk, whose exit depths carry fp32 noise of up to ~1e-5 of a cell, asks for 2^-12), and for
-// faces steep against the rays the rounding of their own plane: the plane is evaluated about the cell's vertex
-// 0, so c and gx * (x - x0) are of the size kappa * extent each and cancel, relative error eps * kappa on
-// gx: eps * kappa^2 * extent, kappa^2 = 1 + gx^2 + gy^2 (times 256: the cell across the interface may be
-// larger); plus the rounding of the absolute depth.  The steep term is capped at 2^-10 of the extent.
-__device__ __forceinline__ double entry_key_slack(double gx, double gy, double c, double extent, double floor_rel) {
-    if (floor_rel < 0.0) return 0.0;  // option "entry_key" 0 (testing): the face's own depth, as before round 3
+// How far an entry's depth key lies behind its face (see next_entry): ONE slack for every face of the frame, plus an
+// extra only for faces steep against the rays.
+//   * uniform: keys shifted by the same amount keep the order of the true depths, so the walk takes a ray's entries in
+//     exactly their order whatever the size of the slack — also a stretch of grid thinner than the slack that is
+//     followed by another entry within it (a first version with a slack per face, proportional to the face's extent,
+//     swapped two such entries in one fuzz scene in 400: a 4.6e-7 chord lost, S off by one; in the mixed walk, whose
+//     slack is larger, 8 in 400).  It only has to exceed the rounding between two evaluations of one plane from
+//     different vertex triples: `base` = 2^-24 of the image domain's extent for the fp64 walk (2.5e-7 on the reference
+//     domain, 1e5 times that rounding), 2^-13 for the mixed walk, whose exit depths carry fp32 rounding of the cell's
+//     size and of the absolute depth (c_api.hip).
+//   * steep faces: the plane is evaluated about the cell's vertex 0, so c and gx * (x - x0) are of the size
+//     kappa * extent each and cancel: relative error eps * kappa on gx, eps * kappa^2 * extent on the depth,
+//     kappa^2 = 1 + gx^2 + gy^2 (times 256: the cell across the interface may be larger; capped at 2^-10 of the
+//     extent).  Only where THAT exceeds the uniform slack does a face get more — those keys can swap with a neighbour
+//     closer than the extra, a face a pixel hits with probability ~1 / kappa.
+// Too small a slack loses the rest of a ray at a non-matching interface; too large a one costs nothing but the swap
+// above.  `base` < 0: no slack at all (option "entry_key" 0, testing: the behaviour before round 3).
+__device__ __forceinline__ double entry_key_slack(double gx, double gy, double extent, double base) {
+    if (base < 0.0) return 0.0;
     const double kappa2 = fma(gx, gx, fma(gy, gy, 1.0));
-    const double steep = fmin(256.0 * DBL_EPSILON * kappa2, 0x1p-10);
-    return fmax(floor_rel, steep) * extent + 64.0 * DBL_EPSILON * fabs(c);
+    const double steep = fmin(256.0 * DBL_EPSILON * kappa2, 0x1p-10) * extent;
+    return fmax(base, steep);
 }
 
 struct RasterArgs {
@@ -345,7 +353,7 @@ struct RasterArgs {
     FrameCounters* counters;
     unsigned* sticky;
     int want_upper;
-    double key_floor;  // entry_key_slack's floor_rel
+    double key_slack;  // entry_key_slack's base: the frame's uniform slack (< 0: none)
 };
 
 // The work of one workgroup (four boundary faces); `block` is its index among the raster workgroups, so that
@@ -434,7 +442,7 @@ __device__ __forceinline__ void entry_raster_block(const GridView& g, const Rast
     // depth key = the face's depth pushed entry_key_slack along the walk (down for upper faces, up for lower ones):
     // once per face, folded into the plane's constant — nothing per pixel
     const double extent = (xmax - xmin) + (ymax - ymin) + (fmax(az, fmax(bz, cz)) - fmin(az, fmin(bz, cz)));
-    const double slack = entry_key_slack(fp.gx, fp.gy, fp.c, extent, A.key_floor);
+    const double slack = entry_key_slack(fp.gx, fp.gy, extent, A.key_slack);
     const double pc = fp.c + (want_upper ? -slack : slack), pgx = fp.gx, pgy = fp.gy;
 
     // The raster is bound by vector instructions (the box of a face holds 2.5x the pixels of the face), so

@@ -117,20 +117,20 @@ void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, 
 
 void launch_entry_lists(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
                         const ImageParams& im, EntryHead* head, Entry* first, Entry* pool, int64_t capacity,
-                        FrameCounters* counters, unsigned* sticky, int want_upper, double key_floor) {
+                        FrameCounters* counters, unsigned* sticky, int want_upper, double key_slack) {
     if (g.n_bfaces <= 0) return;
     const unsigned blocks = static_cast<unsigned>((g.n_bfaces + 3) / 4);
-    const RasterArgs A{Xtab, Ytab, im, head, first, pool, capacity, counters, sticky, want_upper, key_floor};
+    const RasterArgs A{Xtab, Ytab, im, head, first, pool, capacity, counters, sticky, want_upper, key_slack};
     hipLaunchKernelGGL(entry_raster, dim3(blocks), dim3(256), 0, s, g, A);
 }
 
 void launch_setup_fused(hipStream_t s, const GridView& g, double alpha_limit, int order, const double* Xtab, const double* Ytab,
                         const ImageParams& im, EntryHead* head, Entry* first, Entry* pool, int64_t capacity,
-                        FrameCounters* counters, unsigned* sticky, int want_upper, double key_floor) {
+                        FrameCounters* counters, unsigned* sticky, int want_upper, double key_slack) {
     const unsigned n_rec = g.n_cells > 0 ? static_cast<unsigned>((g.n_cells + 255) / 256) : 0u;
     const unsigned n_ras = g.n_bfaces > 0 ? static_cast<unsigned>((g.n_bfaces + 3) / 4) : 0u;
     if (n_rec + n_ras == 0u) return;
-    const RasterArgs A{Xtab, Ytab, im, head, first, pool, capacity, counters, sticky, want_upper, key_floor};
+    const RasterArgs A{Xtab, Ytab, im, head, first, pool, capacity, counters, sticky, want_upper, key_slack};
     hipLaunchKernelGGL(setup_fused, dim3(n_rec + n_ras), dim3(256), 0, s, g, alpha_limit, order, n_rec, n_ras, A);
 }
 
