@@ -133,7 +133,7 @@ int c5_set_row_tiles(c5_context* ctx, int tile_rows, int rank, int world);
  * setup.  Default: the whole image. */
 int c5_set_row_range(c5_context* ctx, int row_begin, int row_count);
 int c5_local_rows(const c5_context* ctx, int* n_rows);
-/* Segments per local row of the last frame (needs option "row_costs" = 1 before rendering):
+/* Segments per local row of the last frame rendered with option "row_costs" = 1 (the option may be off again since):
  * the cost estimate for balancing row blocks across GPUs. */
 int c5_get_row_costs(c5_context* ctx, uint32_t* costs, int n_rows);
 /* View transform of the volume grid (main.cpp:105-107) and of each solid (main.cpp:112-114,
@@ -197,7 +197,14 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  (c5_stats.pool_entries) fits; the library keeps the pool at twice the demand of the
  *                  last frame it looked at and reports C5_RETRY for frames that did not fit.
  *   "lds_pad"      tuning: extra dynamic LDS per workgroup in bytes, to cap the resident wavefronts.
- *   "row_costs"    1: walk_composite also accumulates segments per image row (c5_get_row_costs).
+ *   "row_costs"    1: walk_composite also accumulates segments per image row (c5_get_row_costs).  May be switched per
+ *                  frame: the costs of the last frame that counted them stay readable until the rows are laid out
+ *                  anew (a sweep probes one frame in many).
+ *   "entry_key"    1 (default): a boundary entry is keyed a slack behind its face, the same slack for every face of the
+ *                  frame (+ more for faces steep against the rays), so that a ray leaving through a face that has no
+ *                  partner with the same three points — hanging nodes: a coarse face against several fine ones — is
+ *                  picked up by the abutting cell (the reference never looks at connectivity, object3d_base.cpp:37-42;
+ *                  DESIGN.md section 5).  0 (testing): keyed at the face's own depth, as before round 3.
  *   "stage_timing" / "walk_timing"  0/1: record HIP events per stage / around walk_composite. */
 int c5_set_option(c5_context* ctx, const char* name, double value);
 
@@ -219,7 +226,10 @@ int c5_synchronize(c5_context* ctx);
  * pageable buffer makes the copy synchronous.  At most C5_HOST_RING frames may be outstanding; every
  * c5_render_host_async is paired, in order, with one c5_render_host_wait, which returns when THAT frame's
  * pixels are in out_host.  C5_RETRY from the wait: that frame and every frame enqueued after it are
- * incomplete (an internal buffer was too small and has been grown) — wait for the rest, discard, render again. */
+ * incomplete (an internal buffer was too small and has been grown) — wait for the rest, discard, render again.
+ * Whichever call notices the overflow first (c5_get_stats, c5_get_row_costs, c5_synchronize between an async and
+ * its wait included) settles it and returns C5_RETRY once; the waits of every frame outstanding at that moment
+ * return C5_RETRY as well, whatever their own status snapshots read. */
 #define C5_HOST_RING 3
 int c5_render_host_async(c5_context* ctx, float* out_host);
 int c5_render_host_wait(c5_context* ctx);
@@ -229,7 +239,8 @@ int c5_render_host_wait(c5_context* ctx);
  * no reassembly (the "N direct copies" of SURVEY.md section 8(e); with 8 GPUs, 8 links instead of the root's one).
  * Paired with c5_render_host_wait like c5_render_host_async. */
 int c5_render_frame_rows_async(c5_context* ctx, float* frame_host);
-/* Pinned host memory for images (hipHostMalloc / hipHostFree). */
+/* Pinned host memory for images (hipHostMalloc with hipHostMallocPortable: several contexts — one per GPU — may copy
+ * their rows into the same frame, c5_render_frame_rows_async / hipHostFree). */
 int c5_host_alloc(c5_context* ctx, size_t bytes, void** out_ptr);
 int c5_host_free(c5_context* ctx, void* ptr);
 

@@ -114,10 +114,14 @@ def write_roofline(tag, walk, c):
             # are full the units are busier than their average over the launch by the ratio of the step rates
             lim["steady_state_frac"] = min(1.0, busiest[1] * tl["steady_over_mean"])
             lim["note"] = ("the busiest unit by its counter, averaged over the launch and (steady_state_frac) while the wavefront slots "
-                           "are full: vector-instruction issue is what a step costs - every vector instruction of a wave64 holds its "
-                           "SIMD for a quad-cycle, fp64 or not (SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU), the walk issues ~84 per "
-                           "wavefront-step; more resident wavefronts, frames overlapped on a second stream and filling the launch's "
-                           "tail buy 0-2.5 % (profiles/" + tag + "_walk_timeline.md, " + tag + "_overlap_probe.md)")
+                           "are full (every vector instruction of a wave64 holds its SIMD for a quad-cycle, fp64 or not: "
+                           "SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU; ~84 per wavefront-step).  Two limits meet here: seven wavefronts "
+                           "x 84 quad-cycles fill 86 % of a SIMD's vector issue in the time ONE wavefront needs for a step, and that "
+                           "time is the step's dependent chain (phases: five LDS round trips, the staging loads, ~200 instructions in "
+                           "sequence) - a lone wavefront steps no faster (scripts/share_probe.py: 1.2 us per step at 30 % of the "
+                           "slots).  Hence: four vector instructions fewer per step change nothing (A/B 0.5419 vs 0.5406 ms), an eighth "
+                           "wavefront nothing, frames overlapped on a second stream +2.4 % (profiles/" + tag + "_overlap_probe.md); only "
+                           "shortening chain AND instruction count together pays (the mixed walk: half the LDS bytes, fp32 planes: -16 %)")
         else:
             lim["note"] = "the busiest unit by its counter over the whole launch"
         out["limiter"] = lim
