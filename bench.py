@@ -81,6 +81,7 @@ def parse():
     p.add_argument("--solids", action="store_true", help="add the Roche lobe and the accretor sphere (generated by the course CLI)")
     p.add_argument("--backend", default="nccl", help="nccl (= RCCL, default); gloo only to rehearse N > 1 on one GPU")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-cpu-reference", action="store_true", help="skip the second CPU figure: the reference's own line.cpp / tetra.cpp object code, one thread (about half a minute)")
     p.add_argument("--no-host-image", action="store_true", help="skip the second figure: frames delivered to host memory")
     p.add_argument("--no-mixed", action="store_true", help="skip the second figure with option \"precision\" 1")
     p.add_argument("--no-native", action="store_true", help="skip the figures of the C++ host (`course --bench`)")
@@ -127,6 +128,25 @@ def cpu_baseline(xyz, cells, alpha, q, rots, res):
                   f"{binning + resolve:.0f} ms; peak RSS of the process {rss1 / 1e6:.2f} GB (before: {rss0 / 1e6:.2f})",
         "value_bin_resolve_only": rx * ry / (binning + resolve) / 1e3,
     }, r["segments"]
+
+
+def cpu_baseline_reference(xyz, cells, alpha, q, rots, res):
+    """The reference-backed checker (oracle/_ref: the reference's OWN line.cpp + tetra.cpp object code, compiled in
+    the build container by oracle/Makefile, driven serially by oracle/ref_driver.cpp; plane.cpp's scan conversion is
+    the restatement of oracle/scan.hpp because plane.cpp needs VTK headers) on the same grid, view and image size:
+    one frame on ONE core, about half a minute.  None where the prebuilt library did not travel."""
+    from oracle import pyoracle
+    if not pyoracle.reference_available():
+        return None
+    rx, ry = res
+    t0 = time.perf_counter()
+    r = pyoracle.Oracle("reference").render(xyz, cells, alpha, q, rots, rx, ry, mg.REFERENCE_BOUNDS)
+    dt = time.perf_counter() - t0
+    return {"value": rx * ry / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference",
+            "sample": f"one whole frame of the same workload ({rx}x{ry}, {r['segments']} segments) through the reference's own line.cpp / "
+                      f"tetra.cpp object code (808-byte line objects, per-pixel std::sort, libm exp), one thread: {dt:.1f} s from the "
+                      "rotation of the tets to the last pixel; plane.cpp's binning restated (oracle/scan.hpp), no VTK load; "
+                      "BASELINE.md section 2 has the complete reference binary at 0.13-0.34 Mrays/s on 8 cores"}
 
 
 def load_roofline_counters():
@@ -720,6 +740,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             sres = tuple(int(v) for v in args.cpu_sample_res.lower().split("x")) if args.cpu_sample_res else (res_x, res_y)
             out["cpu_baseline"], _ = cpu_baseline(xyz, cells, alpha, q, rots, sres)
+            if not args.no_cpu_reference:
+                ref_line = cpu_baseline_reference(xyz, cells, alpha, q, rots, sres)
+                if ref_line:
+                    out["cpu_baseline_reference"] = ref_line
         print(json.dumps(out), flush=True)
 
     ctx.close()

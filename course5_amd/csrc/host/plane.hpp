@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "course5_hip.h"
+#include "row_blocks.hpp"
 #include "scene.hpp"
 
 // Pinned host images, recycled: a 2400x1800 frame is 34.6 MB, and pinning memory costs milliseconds.
@@ -162,11 +163,6 @@ std::array<double, 4> bounding_box(std::vector<object3d_base>& objects3d);
 // peer landing a whole block of rows at its offset — move the right bytes, the device sending to itself.  Returns a
 // line for the log; throws on any failure.
 std::string rccl_selftest(int device);
-
-// Contiguous blocks of (nearly) equal cost: cost of a row = its segments + base_cost_per_pixel * res_x (the work
-// every pixel costs regardless: entry lookup, store).  Every device gets at least one row.  The same partition
-// course5_amd/sharding.py: balanced_blocks computes (tests compare the two).
-std::vector<std::pair<int, int>> balanced_row_blocks(const std::vector<uint32_t>& row_cost, int world, double base_cost_per_row);
 
 // "0", "0-7", "0,2,4", "0,0" (the same GPU twice: rehearsal of the multi-GPU path on one GPU)
 std::vector<int> parse_device_list(const std::string& text);

@@ -9,6 +9,7 @@
 //   host_san cli    <args...>               the option parser on the given command line
 //   host_san solids                         init_polar: Roche lobe + sphere, unique faces -> counts
 //   host_san oracle <scene.bin> <out.f32>   the CPU oracle on a dumped scene (see the pytest for the layout)
+//   host_san blocks <world> <base> <c0> <c1> ...  cost-balanced row blocks of the native multi-GPU host
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -23,6 +24,7 @@
 #include "adjacency.hpp"
 #include "cli.hpp"
 #include "config.hpp"
+#include "row_blocks.hpp"
 #include "scene.hpp"
 #include "vtk_io.hpp"
 
@@ -102,6 +104,13 @@ int main(int argc, char** argv) try {
             c5::unique_solid_faces(d.soup.data(), static_cast<int64_t>(d.soup.size() / 12), pts, faces);
             std::printf("solid cells %zu unique points %zu unique faces %zu\n", d.size(), pts.size() / 3, faces.size() / 4);
         }
+        return 0;
+    }
+    if (mode == "blocks") {
+        if (argc < 5) throw std::runtime_error("blocks: world base costs...");
+        std::vector<uint32_t> cost;
+        for (int k = 4; k < argc; ++k) cost.push_back(static_cast<uint32_t>(std::strtoul(argv[k], nullptr, 10)));
+        for (const auto& b : balanced_row_blocks(cost, std::atoi(argv[2]), std::atof(argv[3]))) std::printf("%d %d\n", b.first, b.second);
         return 0;
     }
     if (mode == "oracle") {

@@ -18,7 +18,7 @@ from course5_amd import meshgen as mg
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SOURCES = ["tests/cpp/host_san_main.cpp", "course5_amd/csrc/host/vtk_io.cpp", "course5_amd/csrc/host/cli.cpp",
-           "course5_amd/csrc/host/scene.cpp", "course5_amd/csrc/adjacency.cpp", "oracle/oracle.cpp"]
+           "course5_amd/csrc/host/scene.cpp", "course5_amd/csrc/host/row_blocks.cpp", "course5_amd/csrc/adjacency.cpp", "oracle/oracle.cpp"]
 
 pytestmark = pytest.mark.skipif(shutil.which("g++") is None, reason="no g++")
 
@@ -163,3 +163,25 @@ def test_oracle_under_the_sanitizers(san, tmp_path, oracle_port):
     san("oracle", tmp_path / "scene.bin", tmp_path / "out.f32")
     (tmp_path / "short.bin").write_bytes((tmp_path / "scene.bin").read_bytes()[:1000])
     assert san("oracle", tmp_path / "short.bin", tmp_path / "o").returncode == 1
+
+
+def test_row_blocks_equal_the_python_partition(san):
+    """The native host's cost-balanced row blocks (csrc/host/row_blocks.cpp) are the partition course5_amd/sharding.py
+    computes for the one-process-per-GPU path: the two multi-GPU paths share a frame the same way."""
+    from course5_amd import sharding
+    rng = np.random.default_rng(3)
+    for trial in range(40):
+        n = int(rng.integers(8, 400))
+        world = int(rng.integers(1, min(9, n)))
+        kind = trial % 4
+        cost = (rng.integers(0, 5000, n) if kind == 0 else np.zeros(n, dtype=np.int64) if kind == 1 else
+                np.r_[np.zeros(n // 3, dtype=np.int64), rng.integers(1000, 90000, n - 2 * (n // 3)), np.zeros(n // 3, dtype=np.int64)] if kind == 2 else
+                np.full(n, 77))
+        base = float(rng.choice([0.0, 1.0, 14400.0]))
+        if base == 0.0 and cost.sum() == 0:
+            base = 1.0
+        p = san("blocks", world, base, *[int(c) for c in cost])
+        assert p.returncode == 0, p.stderr
+        got = [tuple(int(v) for v in line.split()) for line in p.stdout.strip().splitlines()]
+        assert got == sharding.balanced_blocks(cost, world, base_cost=base), (trial, n, world, base)
+    assert san("blocks", 5, 1.0, 1, 2, 3).returncode == 1  # more devices than rows: a message
