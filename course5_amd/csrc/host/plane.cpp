@@ -529,13 +529,19 @@ void plane::find_intersections() {
 // cheaper than it is now, the next find_intersections lays the rows out anew.
 void plane::read_row_costs() {
     _row_cost.assign(_y, 0);
+    bool complete = true;
     for (std::size_t r = 0; r < _ctx.size(); ++r) {
         const int n = _blocks[r].second;
         if (n <= 0) continue;
         const int rc = c5_get_row_costs(_ctx[r], _row_cost.data() + _blocks[r].first, n);
-        if (rc == C5_RETRY) _retry_seen[r] = 1;  // (the costs are of an earlier, complete frame; the frames in flight are not)
-        else check(rc, "c5_get_row_costs", r);
+        if (rc == C5_RETRY) {  // a frame in flight behind the probe overflowed: remembered for its trace_rays; no costs this time
+            _retry_seen[r] = 1;
+            complete = false;
+        } else {
+            check(rc, "c5_get_row_costs", r);
+        }
     }
+    if (!complete) return;  // the next probe frame decides
     const double base = kRowBaseCost * static_cast<double>(_x);
     const std::vector<std::pair<int, int>> want = balanced_row_blocks(_row_cost, static_cast<int>(_ctx.size()), base);
     auto dearest = [&](const std::vector<std::pair<int, int>>& blocks) {
