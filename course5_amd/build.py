@@ -32,15 +32,24 @@ LIB_SOURCES = [
 ]
 
 
+DEVICE_SOURCES = ("device_types.hpp", "kernels.hpp", "walk_common.hpp", "walk_mixed_common.hpp", "exact_kernels.hip",
+                  "walk_kernels.hip", "walk_mixed.hip")
+
+
 def kernel_source_hash() -> str:
-    """sha256 over the device-side sources (csrc/*.hip, *.hpp), in name order: committed profiles carry the hash of
-    the sources they were measured on, and bench.py says when the sources have moved on since."""
+    """sha256 over the device-side sources with comments and white space removed: committed profiles carry the hash
+    of the kernels they were measured on, and bench.py says when the kernels have moved on since (an edited comment or
+    a change to the host side of the ABI does not make a profile stale)."""
     import hashlib
+    import re
     h = hashlib.sha256()
-    for name in sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))):
+    for name in DEVICE_SOURCES:
+        with open(os.path.join(CSRC, name)) as f:
+            text = f.read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
         h.update(name.encode())
-        with open(os.path.join(CSRC, name), "rb") as f:
-            h.update(f.read())
+        h.update("".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 

@@ -142,6 +142,8 @@ struct c5_context {
     int solid_cache = 1;    // a solid unchanged since the frame before is not rastered again (enqueue_solids)
     int overlap_setup = 0;  // measured: 1.27 vs 1.26 ms/frame, the side stream buys nothing
     DeviceBuffer px, py, pz, cell_vert, cell_adj, alpha, q, bface;
+    double grid_diagonal = 0.0;  // of the grid's bounding box in object space: no rotation makes the grid longer along a ray
+    double coord_max = 0.0;      // largest |coordinate| (what the rounding of an absolute depth scales with)
     FrameSlot slots[kFrameSlots];
     int64_t frame_index = 0;
     int last_slot = 0;
@@ -532,8 +534,12 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     const bool fused = !mixed && ctx->fuse_setup && !side && g.n_cells > 0;
     if (!fused) C5_HIP(ctx, mark(2, s));
     // boundary entries: one raster pass (per-pixel count + first entry + overflow chain)
-    const double domain = std::fabs(ctx->bounds[0] - ctx->bounds[1]) + std::fabs(ctx->bounds[2] - ctx->bounds[3]);
-    const double key_slack = !ctx->entry_key ? -1.0 : (mixed ? c5::kEntryKeySlackMixed : c5::kEntryKeySlack) * domain;
+    // the frame's uniform entry-key slack (walk_common.hpp: entry_key_slack): a fraction of the GRID's size — not of
+    // the image domain's: a slack larger than a whole ray would let a pixel that two boundary faces both claim (its
+    // centre exactly on their common edge) walk the same cells twice — plus the rounding of an absolute depth
+    const double key_slack = !ctx->entry_key ? -1.0
+                             : (mixed ? c5::kEntryKeySlackMixed * ctx->grid_diagonal + 0x1p-22 * ctx->coord_max
+                                      : c5::kEntryKeySlack * ctx->grid_diagonal + 0x1p-40 * ctx->coord_max);
     if (!fs.head_clean) C5_HIP(ctx, hipMemsetAsync(fs.head.ptr, 0, static_cast<size_t>(padded) * sizeof(c5::EntryHead), e));
     fs.head_clean = false;
     if (fused) {
@@ -1025,6 +1031,20 @@ int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int3
     }
     if (!bfaces.empty())
         C5_HIP(ctx, hipMemcpy(ctx->bface.ptr, bfaces.data(), bfaces.size() * 4, hipMemcpyHostToDevice));
+    {
+        double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, top = 0.0;
+        for (int64_t i = 0; i < n_pts; ++i)
+            for (int k = 0; k < 3; ++k) {
+                const double v = xyz[3 * i + k];
+                lo[k] = i ? std::fmin(lo[k], v) : v;
+                hi[k] = i ? std::fmax(hi[k], v) : v;
+                top = std::fmax(top, std::fabs(v));
+            }
+        ctx->grid_diagonal = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+        // (the view rotates about x = x0 of each rotation: a point's distance from that axis, hence its depth, stays
+        // within the largest |coordinate| + |x0|; the constant below has room for both)
+        ctx->coord_max = top + 2.0;
+    }
     ctx->n_pts = n_pts;
     ctx->n_cells = n_cells;
     ctx->n_bfaces = static_cast<int64_t>(bfaces.size());

@@ -96,7 +96,8 @@ void launch_mask_overlay(hipStream_t s, const uint32_t* src, uint32_t* dst, int6
 
 // walk_kernels.hip
 // key_slack of the two launchers below: how far an entry's depth key lies behind its face (walk_common.hpp:
-// entry_key_slack) = this fraction of the image domain's extent (x range + y range), the same for every face
+// entry_key_slack) = this fraction of the diagonal of the grid's bounding box (+ a term for the rounding of an
+// absolute depth, c_api.hip), the same for every face of a frame
 constexpr double kEntryKeySlack = 0x1p-24;       // fp64 walk
 constexpr double kEntryKeySlackMixed = 0x1p-13;  // "precision" 1: exit depths carry fp32 rounding
 // with_optics: also rebuild the cells' optics (view-independent: only when scalars, alpha limit or order changed)

@@ -325,9 +325,10 @@ __device__ __forceinline__ int next_entry(const WalkParams& P, size_t lp, EntryH
 //     followed by another entry within it (a first version with a slack per face, proportional to the face's extent,
 //     swapped two such entries in one fuzz scene in 400: a 4.6e-7 chord lost, S off by one; in the mixed walk, whose
 //     slack is larger, 8 in 400).  It only has to exceed the rounding between two evaluations of one plane from
-//     different vertex triples: `base` = 2^-24 of the image domain's extent for the fp64 walk (2.5e-7 on the reference
-//     domain, 1e5 times that rounding), 2^-13 for the mixed walk, whose exit depths carry fp32 rounding of the cell's
-//     size and of the absolute depth (c_api.hip).
+//     different vertex triples: `base` = 2^-24 of the grid's bounding-box diagonal for the fp64 walk (1e-7 on the C3
+//     grid, 1e5 times that rounding), 2^-13 for the mixed walk, whose exit depths carry fp32 rounding of the cell's
+//     size and of the absolute depth (c_api.hip).  Tied to the GRID's size: a slack longer than a whole ray would let
+//     a pixel that two boundary faces both claim (centre exactly on their common edge) walk the same cells twice.
 //   * steep faces: the plane is evaluated about the cell's vertex 0, so c and gx * (x - x0) are of the size
 //     kappa * extent each and cancel: relative error eps * kappa on gx, eps * kappa^2 * extent on the depth,
 //     kappa^2 = 1 + gx^2 + gy^2 (times 256: the cell across the interface may be larger; capped at 2^-10 of the
