@@ -149,3 +149,38 @@ def test_refined_interface_at_scale(gpu_ctx, oracle_port):
     assert st["segments"] == ref["segments"] and st["covered_pixels"] == ref["covered"]
     r = assert_images_match(img, ref["image"], "refined interface 24")
     assert r["differing"] <= img.size // 1000, r
+
+
+@pytest.mark.parametrize("view", [(0.1, 0.07), (0.37, -0.61)], ids=["bench-view", "oblique"])
+def test_refined_interface_at_the_benchmark_size(gpu_ctx, oracle_port, view):
+    """BASELINE's own scale: 98 304 coarse + 786 432 fine cells (884 736; 2 048 coarse interface faces against
+    8 192 fine ones) at 2400x1800 — every pixel of the frame, S and covered against the CPU oracle, in the fp64 walk
+    (both orders) and the mixed walk, plus an 8-way cyclic split reassembled bit for bit.  In the bench view the
+    interface is seen at 13 degrees (5 % of the rays cross it), in the oblique one most rays do."""
+    xyz, cells, n_coarse = mg.refined_interface(32, 16, 32, lo=(0.5, -0.5, -0.5), size=1.0, jitter=0.1, warp=0.05, seed=77)
+    assert n_coarse == 98_304 and len(cells) == 884_736
+    alpha, q = mg.scalars(len(cells), seed=78)
+    rots = mg.view_rotations(*view)
+    gpu_ctx.upload_grid(xyz, cells, alpha, q)
+    ref = oracle_port.render(xyz, cells, alpha, q, rots, 2400, 1800, mg.REFERENCE_BOUNDS, threads=16)
+    full, st = _frame(gpu_ctx, rots, 2400, 1800)
+    assert st["segments"] == ref["segments"] and st["covered_pixels"] == ref["covered"]
+    assert st["entries"] > st["covered_pixels"] * (1.03 if view == (0.1, 0.07) else 1.4)  # rays that cross the interface enter twice
+    r = assert_images_match(full, ref["image"], f"refined interface, 884 736 cells, 2400x1800, view {view}")
+    assert r["differing"] <= full.size // 1000, r
+    gpu_ctx.set_option("integration", 1)
+    img, st1 = _frame(gpu_ctx, rots, 2400, 1800)
+    assert st1["segments"] == ref["segments"]
+    assert_images_match(img, ref["image"], "front to back")
+    gpu_ctx.set_option("integration", 0)
+    gpu_ctx.set_option("precision", 1)
+    img, stm = _frame(gpu_ctx, rots, 2400, 1800)
+    gpu_ctx.set_option("precision", 0)
+    assert_images_match(img, ref["image"], "mixed walk")
+    assert abs(stm["segments"] - ref["segments"]) <= ref["segments"] // 5000
+    strips = []
+    for rank in range(8):
+        gpu_ctx.set_row_tiles(16, rank, 8)
+        strips.append(gpu_ctx.render())
+    gpu_ctx.set_row_tiles(0, 0, 1)
+    assert np.array_equal(sharding.assemble(strips, 1800, 16, 8).view(np.uint32), full.view(np.uint32))
