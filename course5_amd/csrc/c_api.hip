@@ -49,10 +49,6 @@ struct DeviceBuffer {
     }
 };
 
-// where a frame's CellOptics start inside its record allocation
-inline size_t optics_offset(int64_t n_cells) {
-    return (static_cast<size_t>(n_cells) * sizeof(c5::CellRecord) + 128 + 255) & ~static_cast<size_t>(255);
-}
 
 struct Solid {
     int64_t n_tets = 0;      // as given
@@ -447,8 +443,8 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     g.alpha = ctx->alpha.as<double>();
     g.q = ctx->q.as<double>();
     g.bface = ctx->bface.as<uint32_t>();
+    g.xrec = fs.rec.as<c5::ExitRecord>();
     g.rec = fs.rec.as<c5::CellRecord>();
-    g.opt = reinterpret_cast<c5::CellOptics*>(static_cast<char*>(fs.rec.ptr) + optics_offset(ctx->n_cells));
     // y band of the rows this context renders (one pixel of slack on both sides)
     if (im.n_local_rows > 0) {
         const int first = c5::global_row_of(im, 0), last = c5::global_row_of(im, im.n_local_rows - 1);
@@ -523,13 +519,8 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
         fs.optics32_valid = true;
         fs.optics32_limit = ctx->alpha_limit;
     } else if (!(ctx->fuse_setup && !side && g.n_cells > 0)) {
-        // the optics of a cell depend on its scalars, the alpha limit and the integration order, on nothing of the
-        // view: rebuilt only when one of those changed (160 instead of 208 bytes of HBM traffic per cell and frame)
-        const bool optics_stale = !ctx->optics_once || !fs.optics_valid || fs.optics_limit != ctx->alpha_limit || fs.optics_order != ctx->order;
-        c5::launch_build_records(s, g, ctx->alpha_limit, ctx->order, optics_stale);
-        fs.optics_valid = true;
-        fs.optics_limit = ctx->alpha_limit;
-        fs.optics_order = ctx->order;
+        // (a cell's optics ride in its record since round 3 — one line per cell and step — and are rewritten with it)
+        c5::launch_build_records(s, g, ctx->alpha_limit, ctx->order);
     }
     const bool fused = !mixed && ctx->fuse_setup && !side && g.n_cells > 0;
     if (!fused) C5_HIP(ctx, mark(2, s));
@@ -548,10 +539,6 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
         c5::launch_setup_fused(s, g, ctx->alpha_limit, ctx->order, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im,
                                fs.head.as<c5::EntryHead>(), fs.first.as<c5::Entry>(), fs.pool.as<c5::Entry>(), fs.entry_capacity,
                                fs.counters.as<c5::FrameCounters>(), ctx->sticky.as<unsigned>(), ctx->order != 0, key_slack);
-        // (the fused launch rewrites every cell's optics for the current limit and order)
-        fs.optics_valid = true;
-        fs.optics_limit = ctx->alpha_limit;
-        fs.optics_order = ctx->order;
         C5_HIP(ctx, mark(2, s));
     } else if (g.n_cells > 0) {
         c5::launch_entry_lists(e, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im, fs.head.as<c5::EntryHead>(),
@@ -573,8 +560,8 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
 
     // (a11-a14) walk on the main stream, after this slot's setup
     c5::WalkParams wp{};
+    wp.xrec = g.xrec;
     wp.rec = g.rec;
-    wp.opt = g.opt;
     wp.geo = g.geo;
     wp.opt32 = g.opt32;
     wp.z0 = g.z0;
@@ -583,6 +570,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     wp.entry_first = fs.first.as<c5::Entry>();
     wp.entry_pool = fs.pool.as<c5::Entry>();
     wp.pool_capacity = fs.entry_capacity;
+    wp.key_slack = key_slack > 0.0 ? key_slack : 0.0;
     wp.mask = any_solid ? fs.mask.as<uint32_t>() : nullptr;
     wp.solids = table;
     wp.Xtab = ctx->xtab.as<double>();
@@ -597,8 +585,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     wp.band_rows = ctx->band_rows;
     wp.order = ctx->order;
     // walk_composite_lds addresses the records by 32-bit byte offsets: n_cells * 128 must fit
-    // (2: LDS-DMA staging — ids times 128 through a 24-bit multiply, optics within 32 bits of the records)
-    wp.lds_stage = (ctx->lds_stage && ctx->n_cells < (int64_t{1} << 25)) ? ((ctx->lds_stage == 2 && ctx->n_cells < (int64_t{1} << 24)) ? 2 : 1) : 0;
+    wp.lds_stage = (ctx->lds_stage && ctx->n_cells < (int64_t{1} << 25)) ? ctx->lds_stage : 0;
     wp.counters = fs.counters.as<c5::FrameCounters>();
     wp.row_cost = nullptr;
     wp.sb_cost = sb;
@@ -1002,9 +989,8 @@ int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int3
         C5_HIP(ctx, fs.vx.ensure(pb ? pb : 8));
         C5_HIP(ctx, fs.vy.ensure(pb ? pb : 8));
         C5_HIP(ctx, fs.vz.ensure(pb ? pb : 8));
-        // records and optics in ONE allocation, the optics behind the records (optics_offset): the staging loads of
-        // walk_composite_lds<.., DMA> reach both with one 32-bit offset from the records
-        C5_HIP(ctx, fs.rec.ensure(optics_offset(n_cells) + cb * sizeof(c5::CellOptics) + 256));
+        // one 128-byte record per cell and view (ExitRecord; "precision" 1 keeps a steep cell's SteepPlanes there)
+        C5_HIP(ctx, fs.rec.ensure(cb * sizeof(c5::ExitRecord) + 256));
         // records of cells outside a context's row band are never rebuilt; keep whatever they hold a
         // valid record (neighbour ids inside the grid) from the start
         C5_HIP(ctx, hipMemset(fs.rec.ptr, 0, fs.rec.bytes));

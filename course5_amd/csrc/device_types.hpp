@@ -53,6 +53,31 @@ struct alignas(16) CellOptics {
 };
 static_assert(sizeof(CellOptics) == 32, "CellOptics is 32 bytes");
 
+// What the fp64 walk reads per step since round 3: ONE 128-byte line per cell and view with only what a ray needs to
+// LEAVE the cell, and the cell's optics beside it.
+//   * exit candidates only: walking along +z (reference order: back to front) a ray leaves through the lowest of the
+//     cell's upper faces, walking along -z through the highest of its lower ones; a tetrahedron has at most three of
+//     either.  The depth at which the ray ENTERED is the depth at which it left the cell before (or the boundary
+//     entry's own depth): the chord is the difference of two consecutive exit depths, so the entry-side planes are
+//     not evaluated at all — 3 planes instead of 4, no upper / lower classification of slots.
+//   * walk coordinate w (grows along the walk): w = z for order 0, w = -z for order 1 (the candidates of order 1 are
+//     stored negated), so that both orders are "w_exit = min over the candidates".
+//   * planes about the ABSOLUTE pixel coordinates, w(x, y) = c + gx x + gy y: no cell-local origin in the record and
+//     no (x - x0, y - y0) per step.  Against the cell-local form this costs rounding of the size eps * kappa * |x|
+//     (kappa = the face's slope against the rays) instead of eps * kappa * extent — far below the fp32 output either
+//     way, and what the entry keys' slack for steep faces already allows for.
+//   * unused candidates: c = +inf, gx = gy = 0 (never the minimum); edge-on faces and flat cells likewise.
+// 16-byte units: 0-4 planes (+ nbr[0..1] in the upper half of unit 4), 5 = {nbr[2], flags, pad}, 6 = {alpha_raw,
+// alpha_c}, 7 = {aux, q} (CellOptics).
+struct alignas(16) ExitRecord {
+    double plane[3][3];
+    uint32_t nbr[3];  // kIdMask bits: neighbour behind candidate k, or kNoCell
+    uint32_t flags;   // spare
+    double pad;
+    double alpha_raw, alpha_c, aux, q;
+};
+static_assert(sizeof(ExitRecord) == 128, "ExitRecord must be one 128-byte line");
+
 // --- "precision" 1: the compact records of walk_composite_mixed --------------------------------------------
 // 64 bytes of geometry per cell, in single precision about a cell-local origin ON THE PIXEL LATTICE:
 //   z(col, row) - z0 = plane[k][0] + plane[k][1] * (col - col0) + plane[k][2] * (row - row0)
@@ -77,11 +102,15 @@ static_assert(sizeof(OptRecord) == 16, "OptRecord is 16 bytes");
 
 // A place where a ray enters the grid through a boundary face.  first[pixel] holds a pixel's first
 // entry; further ones live in the overflow pool, chained through `next` (pool slot + 1, 0 = end).
+// z: the entry face's own depth at the pixel.  cell: bits 0-27 the cell, bits 28-31 k: the entry is KEYED at its
+// depth pushed (frame's uniform slack) * 2^k along the walk (k > 0 only for faces steep against the rays;
+// walk_common.hpp: next_entry, entry_key_slack).
 struct alignas(16) Entry {
     double z;
-    int32_t cell;
+    uint32_t cell;
     int32_t next;
 };
+constexpr int kEntrySlackShift = 28;
 // Per pixel and frame: number of entries and the head of the pixel's overflow chain (pool slot + 1).
 // Cleared to zero before every raster pass.
 struct alignas(8) EntryHead {

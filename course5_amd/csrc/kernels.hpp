@@ -18,8 +18,8 @@ struct GridView {  // device pointers of the persistent grid + per-view buffers
     const int4* cell_adj = nullptr;
     const double *alpha = nullptr, *q = nullptr;
     const uint32_t* bface = nullptr;
-    CellRecord* rec = nullptr;
-    CellOptics* opt = nullptr;
+    ExitRecord* xrec = nullptr;  // fp64 walk: one 128-byte line per cell and view (exit candidates + optics)
+    CellRecord* rec = nullptr;   // the same allocation seen as the mixed walk's SteepPlanes slots ("precision" 1)
     // "precision" 1 (walk_mixed.hip): compact single-precision records instead of rec / opt
     GeoRecord* geo = nullptr;
     OptRecord* opt32 = nullptr;
@@ -29,8 +29,8 @@ struct GridView {  // device pointers of the persistent grid + per-view buffers
 };
 
 struct WalkParams {
-    const CellRecord* rec;
-    const CellOptics* opt;
+    const ExitRecord* xrec;
+    const CellRecord* rec;      // "precision" 1: SteepPlanes
     const GeoRecord* geo;       // "precision" 1
     const OptRecord* opt32;
     const float* z0;
@@ -39,6 +39,7 @@ struct WalkParams {
     const Entry* entry_first;   // [n_local_px] first entry (valid where entry_count > 0)
     const Entry* entry_pool;    // overflow entries, chained from entry_first[].next
     int64_t pool_capacity;
+    double key_slack;           // the frame's uniform entry-key slack (walk_common.hpp: next_entry); 0: keys = depths
     const uint32_t* mask;       // [n_local_px] or nullptr
     SolidTable solids;
     const double* Xtab;
@@ -50,7 +51,7 @@ struct WalkParams {
     int32_t xcd_mode;
     int32_t band_tiles;         // xcd_mode 1: workgroup-tile rows per band (set by launch_walk)
     int32_t lds_stage;          // 2: walk_composite_lds with LDS-DMA staging, 1: staged through registers, 0: direct loads
-    int32_t stage_slots;        // lds_stage 2: 16 or 24 distinct cells staged per wavefront and step
+    int32_t stage_slots;        // lds_stage 1 / 2: <= 16 -> 14, more -> 21 distinct cells staged per wavefront and step (2 / 3 DMA passes of 7)
     int32_t band_rows;          // xcd_mode 1: image rows per band (0: 32)
     int32_t lds_pad;            // tuning: extra dynamic LDS per workgroup (bytes) to cap the resident wavefronts
     int32_t order;              // 0: back to front in the reference's arithmetic; 1: front to back + early-out
@@ -100,8 +101,7 @@ void launch_mask_overlay(hipStream_t s, const uint32_t* src, uint32_t* dst, int6
 // absolute depth, c_api.hip), the same for every face of a frame
 constexpr double kEntryKeySlack = 0x1p-24;       // fp64 walk
 constexpr double kEntryKeySlackMixed = 0x1p-13;  // "precision" 1: exit depths carry fp32 rounding
-// with_optics: also rebuild the cells' optics (view-independent: only when scalars, alpha limit or order changed)
-void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, int order, bool with_optics);
+void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, int order);
 void launch_entry_lists(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
                         const ImageParams& im, EntryHead* head, Entry* first, Entry* pool, int64_t capacity,
                         FrameCounters* counters, unsigned* sticky, int want_upper, double key_slack);

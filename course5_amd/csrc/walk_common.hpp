@@ -173,6 +173,44 @@ __device__ __forceinline__ bool build_cell_impl(const GridView& g, double alpha_
     return true;
 }
 
+// The cell's ExitRecord (device_types.hpp) from its walk-order record: the candidates a ray can LEAVE through — the upper
+// slots walking along +z (order 0), the lower ones walking along -z (order 1, stored negated: w = -z) — as planes about
+// the absolute pixel coordinates, and the optics.
+__device__ __forceinline__ void to_exit_record(const CellRecord& r, const CellOptics& o, int order, ExitRecord& x) {
+    const int n_up = static_cast<int>(r.nbr[0] >> kUpperCountShift);  // slots 0 .. n_up - 1 upper, the rest lower
+    const double sign = order == 0 ? 1.0 : -1.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        // order 0: candidates = slots 0, 1, 2 while they are upper; order 1: slots 3, 2, 1 while they are lower
+        const int slot = order == 0 ? k : 3 - k;
+        const bool is_candidate = order == 0 ? (slot < n_up) : (slot >= n_up);
+        double c = INFINITY, gx = 0.0, gy = 0.0;
+        uint32_t w = kNoCell;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // selects, not runtime indexing
+            if (j == slot && is_candidate) {
+                const double pc = r.plane[j][0], pgx = r.plane[j][1], pgy = r.plane[j][2];
+                if (fabs(pc) <= DBL_MAX) {  // (an edge-on slot or a flat cell carries +-inf: never an exit)
+                    gx = sign * pgx;
+                    gy = sign * pgy;
+                    c = sign * (pc - pgx * r.x0 - pgy * r.y0);
+                    w = r.nbr[j] & kIdMask;
+                }
+            }
+        }
+        x.plane[k][0] = c;
+        x.plane[k][1] = gx;
+        x.plane[k][2] = gy;
+        x.nbr[k] = w;
+    }
+    x.flags = 0u;
+    x.pad = 0.0;
+    x.alpha_raw = o.alpha_raw;
+    x.alpha_c = o.alpha_c;
+    x.aux = o.aux;
+    x.q = o.q;
+}
+
 template <int TILE>
 struct TileShape;
 template <>
@@ -271,38 +309,42 @@ __device__ __forceinline__ EntryHead load_entry_head(const EntryHead* p) {
     return h;
 }
 
-// next place the ray enters the grid beyond s_cur (s = z walking down, -z walking up); -1 if none.
-// The pixel's entries are first[lp] and the chain through the overflow pool (entry_raster).
+// Next place the ray enters the grid beyond w_cur, in the walk coordinate w (w = z walking along +z, order 0; w = -z
+// walking along -z; w grows along the walk): the cell, or -1 if there is none.  The pixel's entries are first[lp] and
+// the chain through the overflow pool (entry_raster).
 //
-// An entry's `z` is a depth KEY, not the entry face's depth: entry_raster pushes it a slack (entry_key_slack, below; the
-// same for every face of the frame) along the walk, INTO the cell the face belongs to.  Where two cells meet at faces that do not match
-// (hanging nodes: a coarse face against several fine ones — conforming in space, not in connectivity; the
-// reference never looks at connectivity, object3d_base.cpp:37-42 + plane.cpp:184-192 + line.cpp:138) both faces
-// are boundary faces, the ray leaves through one and has to enter through the other AT THE SAME DEPTH — the same
-// plane evaluated from two different vertex triples, equal only to rounding.  With the face's own depth as the
-// key the strict comparison below is a coin toss per crossing, and a lost toss loses the rest of the ray.  With
-// the key pushed into the cell, "the nearest key beyond where the ray left the grid" finds the abutting cell
-// whichever way the rounding fell, and never an entry already used: s_cur is moved to the key taken, and keys
-// are compared strictly.
+// Entries are compared by a depth KEY, not by the entry face's depth: the depth pushed a slack along the walk, INTO
+// the cell the face belongs to (P.key_slack, the same for every face of the frame; times 2^k for a face steep
+// against the rays, k in the entry's cell word).  Where two cells meet at faces that do not match (hanging nodes: a
+// coarse face against several fine ones — conforming in space, not in connectivity; the reference never looks at
+// connectivity, object3d_base.cpp:37-42 + plane.cpp:184-192 + line.cpp:138) both faces are boundary faces, the ray
+// leaves through one and has to enter through the other AT THE SAME DEPTH — the same plane evaluated from two
+// different vertex triples, equal only to rounding.  With the face's own depth as the key a strict comparison is a
+// coin toss per crossing, and a lost toss loses the rest of the ray.  With the key pushed into the cell, "the nearest
+// key beyond where the ray left the grid" finds the abutting cell whichever way the rounding fell, and never an entry
+// already used: w_cur is moved to the key taken, and keys are compared strictly.
+// On return w_entry = the entry's OWN depth (where the chord through its cell starts).
 template <bool kUp>
-__device__ __forceinline__ int next_entry(const WalkParams& P, size_t lp, EntryHead h, double& s_cur) {
-    double s_best = -DBL_MAX;
+__device__ __forceinline__ int next_entry(const WalkParams& P, size_t lp, EntryHead h, double& w_cur, double& w_entry) {
+    double key_best = DBL_MAX;
     int cell = -1;
     const Entry* e = P.entry_first + lp;
     int hop = h.chain;
     for (int k = 0; k < h.count; ++k) {  // bounded by the count: a chain cut short by a pool overflow ends at hop 0
         const double z = e->z;
-        const int c = e->cell;
-        const double se = kUp ? -z : z;
-        if (se < s_cur && se > s_best) {
-            s_best = se;
-            cell = c;
+        const uint32_t word = e->cell;
+        const double we = kUp ? z : -z;
+        const double key = we + ldexp(P.key_slack, static_cast<int>(word >> kEntrySlackShift));
+        if (key > w_cur && key < key_best) {
+            key_best = key;
+            cell = static_cast<int>(word & kIdMask);
+            w_entry = we;
         }
         if (hop <= 0 || hop > P.pool_capacity) break;
         e = P.entry_pool + (hop - 1);
         hop = e->next;
     }
-    if (cell >= 0) s_cur = s_best;
+    if (cell >= 0) w_cur = key_best;
     return cell;
 }
 
@@ -318,8 +360,8 @@ __device__ __forceinline__ int next_entry(const WalkParams& P, size_t lp, EntryH
 // (count -> scan -> fill took 35 + 30 + 52 us on the C3 frame); first[] is never cleared, only the
 // 8-byte heads are.
 // ------------------------------------------------------------------------------------------
-// How far an entry's depth key lies behind its face (see next_entry): ONE slack for every face of the frame, plus an
-// extra only for faces steep against the rays.
+// How far an entry's depth key lies behind its face (see next_entry): ONE slack for every face of the frame, times a
+// power of two only for faces steep against the rays.
 //   * uniform: keys shifted by the same amount keep the order of the true depths, so the walk takes a ray's entries in
 //     exactly their order whatever the size of the slack — also a stretch of grid thinner than the slack that is
 //     followed by another entry within it (a first version with a slack per face, proportional to the face's extent,
@@ -329,18 +371,21 @@ __device__ __forceinline__ int next_entry(const WalkParams& P, size_t lp, EntryH
 //     grid, 1e5 times that rounding), 2^-13 for the mixed walk, whose exit depths carry fp32 rounding of the cell's
 //     size and of the absolute depth (c_api.hip).  Tied to the GRID's size: a slack longer than a whole ray would let
 //     a pixel that two boundary faces both claim (centre exactly on their common edge) walk the same cells twice.
-//   * steep faces: the plane is evaluated about the cell's vertex 0, so c and gx * (x - x0) are of the size
-//     kappa * extent each and cancel: relative error eps * kappa on gx, eps * kappa^2 * extent on the depth,
-//     kappa^2 = 1 + gx^2 + gy^2 (times 256: the cell across the interface may be larger; capped at 2^-10 of the
-//     extent).  Only where THAT exceeds the uniform slack does a face get more — those keys can swap with a neighbour
-//     closer than the extra, a face a pixel hits with probability ~1 / kappa.
+//   * steep faces: a plane's depth is c + gx x + gy y with |gx x| of the size kappa * |x|: rounding eps * kappa * |x|,
+//     and kappa * (the relative error of gx) * extent = eps * kappa^2 * extent on top, kappa^2 = 1 + gx^2 + gy^2
+//     (times 256: the cell across the interface may be larger; capped at 2^-10 of the extent).  Only where THAT exceeds
+//     the uniform slack does a face get more: the smallest k with base * 2^k above it (k <= 15) — those keys can swap
+//     with a neighbour closer than their slack, a face a pixel hits with probability ~1 / kappa.
 // Too small a slack loses the rest of a ray at a non-matching interface; too large a one costs nothing but the swap
-// above.  `base` < 0: no slack at all (option "entry_key" 0, testing: the behaviour before round 3).
-__device__ __forceinline__ double entry_key_slack(double gx, double gy, double extent, double base) {
-    if (base < 0.0) return 0.0;
+// above.  base <= 0: no slack at all (option "entry_key" 0, testing: the behaviour before round 3).
+__device__ __forceinline__ uint32_t entry_key_exponent(double gx, double gy, double extent, double coord, double base) {
+    if (!(base > 0.0)) return 0u;
     const double kappa2 = fma(gx, gx, fma(gy, gy, 1.0));
-    const double steep = fmin(256.0 * DBL_EPSILON * kappa2, 0x1p-10) * extent;
-    return fmax(base, steep);
+    const double steep = fmin(256.0 * DBL_EPSILON * kappa2, 0x1p-10) * extent + 64.0 * DBL_EPSILON * sqrt(kappa2) * coord;
+    if (!(steep > base)) return 0u;
+    int e = 0;
+    (void)frexp(steep / base, &e);  // steep / base = m * 2^e, 0.5 <= m < 1: 2^e >= the ratio
+    return static_cast<uint32_t>(e < 1 ? 1 : (e > 15 ? 15 : e));
 }
 
 struct RasterArgs {
@@ -354,7 +399,7 @@ struct RasterArgs {
     FrameCounters* counters;
     unsigned* sticky;
     int want_upper;
-    double key_slack;  // entry_key_slack's base: the frame's uniform slack (< 0: none)
+    double key_slack;  // the frame's uniform entry-key slack (entry_key_exponent's base; <= 0: none)
 };
 
 // The work of one workgroup (four boundary faces); `block` is its index among the raster workgroups, so that
@@ -440,11 +485,12 @@ __device__ __forceinline__ void entry_raster_block(const GridView& g, const Rast
     const unsigned n_box = bw * static_cast<unsigned>(lr1 - lr0 + 1);  // <= pixels of the image: fits 32 bits
 
     const double x0 = p[0][0], y0 = p[0][1];
-    // depth key = the face's depth pushed entry_key_slack along the walk (down for upper faces, up for lower ones):
-    // once per face, folded into the plane's constant — nothing per pixel
+    // an entry carries its face's own depth; how far behind it the entry is KEYED is the frame's uniform slack times
+    // 2^k, k > 0 only for a face steep against the rays: once per face, in the top bits of the cell word
     const double extent = (xmax - xmin) + (ymax - ymin) + (fmax(az, fmax(bz, cz)) - fmin(az, fmin(bz, cz)));
-    const double slack = entry_key_slack(fp.gx, fp.gy, extent, A.key_slack);
-    const double pc = fp.c + (want_upper ? -slack : slack), pgx = fp.gx, pgy = fp.gy;
+    const double coord = fmax(fmax(fabs(xmin), fabs(xmax)), fmax(fabs(ymin), fabs(ymax)));
+    const uint32_t cell_word = cell | (entry_key_exponent(fp.gx, fp.gy, extent, coord, A.key_slack) << kEntrySlackShift);
+    const double pc = fp.c, pgx = fp.gx, pgy = fp.gy;
 
     // The raster is bound by vector instructions (the box of a face holds 2.5x the pixels of the face), so
     // the per-pixel work is kept small: the three edge functions as planes about vertex a (two fused
@@ -516,7 +562,7 @@ __device__ __forceinline__ void entry_raster_block(const GridView& g, const Rast
             if (in[k] && old[k] == 0) {
                 Entry e;
                 e.z = z[k];
-                e.cell = static_cast<int32_t>(cell);
+                e.cell = cell_word;
                 e.next = 0;
                 first[lp[k]] = e;
             }
@@ -561,7 +607,7 @@ __device__ __forceinline__ void entry_raster_block(const GridView& g, const Rast
             if (more && slot >= 0) {
                 Entry e;
                 e.z = z[k];
-                e.cell = static_cast<int32_t>(cell);
+                e.cell = cell_word;
                 e.next = atomicExch(&head[lp[k]].chain, static_cast<int32_t>(slot) + 1);
                 pool[slot] = e;
             }

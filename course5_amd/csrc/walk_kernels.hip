@@ -26,66 +26,45 @@
 
 namespace c5 {
 
-// One thread builds one cell's records in registers; a wavefront then writes its 64 records through a
+// One thread builds one cell's record in registers; a wavefront then writes its 64 records through a
 // wave-private LDS area so that every store instruction covers 1 KiB of consecutive addresses (a
 // thread storing its own 128-byte record would touch 64 different lines per instruction).
 struct alignas(16) Q4 {
     uint32_t a, b, c, d;
 };
 constexpr int kRecPad = 9;  // 16-byte units per record in LDS: 8 + 1 pad (conflict-free b128 rows)
-constexpr int kOptPad = 3;  // 2 + 1 pad
 
-// kOptics: also (re)build the cells' optics — of EVERY cell, the ones outside this context's row band included,
-// since they depend on nothing of the view and are not rebuilt until the scalars, the limit or the order change.
-template <bool kOptics>
 __device__ __forceinline__ void build_records_block(const GridView& g, double alpha_limit, int order, unsigned block,
-                                                    Q4 (*s_rec)[64 * kRecPad], Q4 (*s_opt)[64 * kOptPad]) {
+                                                    Q4 (*s_rec)[64 * kRecPad]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t cell = block * static_cast<int64_t>(blockDim.x) + threadIdx.x;
     const int64_t wave_first = cell - lane;
-    const bool in_grid = cell < g.n_cells;
-    bool valid = in_grid;
+    bool valid = cell < g.n_cells;
     CellRecord r;
     CellOptics o;
-    if (valid) valid = build_cell_impl<false>(g, alpha_limit, order, cell, r, o, nullptr);
+    if (valid) valid = build_cell_impl<true>(g, alpha_limit, order, cell, r, o, nullptr);
     const unsigned long long valid_mask = __builtin_amdgcn_ballot_w64(valid);
-    const unsigned long long grid_mask = kOptics ? __builtin_amdgcn_ballot_w64(in_grid) : 0ull;
-    if ((valid_mask | grid_mask) == 0ull) return;  // wave-uniform
+    if (valid_mask == 0ull) return;  // wave-uniform
     Q4* const my_rec = s_rec[wave];
-    Q4* const my_opt = s_opt[wave];
     if (valid) {
-        const Q4* rp = reinterpret_cast<const Q4*>(&r);
+        ExitRecord x;
+        to_exit_record(r, o, order, x);
+        const Q4* rp = reinterpret_cast<const Q4*>(&x);
 #pragma unroll
         for (int k = 0; k < 8; ++k) my_rec[lane * kRecPad + k] = rp[k];
     }
-    if (kOptics && in_grid) {
-        o = cell_optics(g, alpha_limit, order, cell);
-        const Q4* op = reinterpret_cast<const Q4*>(&o);
-        my_opt[lane * kOptPad] = op[0];
-        my_opt[lane * kOptPad + 1] = op[1];
-    }
     __builtin_amdgcn_wave_barrier();
-    Q4* const rec_out = reinterpret_cast<Q4*>(g.rec + wave_first);
+    Q4* const rec_out = reinterpret_cast<Q4*>(g.xrec + wave_first);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {  // 8 x 1 KiB: records 8k .. 8k+7 of the wavefront
         const int rec_i = k * 8 + (lane >> 3);
         if ((valid_mask >> rec_i) & 1ull) rec_out[k * 64 + lane] = my_rec[rec_i * kRecPad + (lane & 7)];
     }
-    if (kOptics) {
-        Q4* const opt_out = reinterpret_cast<Q4*>(g.opt + wave_first);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {  // 2 x 1 KiB of optics
-            const int opt_i = k * 32 + (lane >> 1);
-            if ((grid_mask >> opt_i) & 1ull) opt_out[k * 64 + lane] = my_opt[opt_i * kOptPad + (lane & 1)];
-        }
-    }
 }
 
-template <bool kOptics>
 __global__ __launch_bounds__(256) void build_records(GridView g, double alpha_limit, int order) {
     __shared__ Q4 s_rec[4][64 * kRecPad];
-    __shared__ Q4 s_opt[4][64 * kOptPad];
-    build_records_block<kOptics>(g, alpha_limit, order, blockIdx.x, s_rec, s_opt);
+    build_records_block(g, alpha_limit, order, blockIdx.x, s_rec);
 }
 
 __global__ __launch_bounds__(256) void entry_raster(GridView g, RasterArgs A) { entry_raster_block(g, A, blockIdx.x); }
@@ -96,23 +75,19 @@ __global__ __launch_bounds__(256) void entry_raster(GridView g, RasterArgs A) { 
 __global__ __launch_bounds__(256) void setup_fused(GridView g, double alpha_limit, int order, unsigned n_rec, unsigned n_ras,
                                                    RasterArgs A) {
     __shared__ Q4 s_rec[4][64 * kRecPad];
-    __shared__ Q4 s_opt[4][64 * kOptPad];
     const unsigned b = blockIdx.x, m = n_rec < n_ras ? n_rec : n_ras;
     const bool raster = b < 2u * m ? (b & 1u) != 0u : n_ras > n_rec;
     const unsigned idx = b < 2u * m ? b >> 1 : b - m;
     if (raster)
         entry_raster_block(g, A, idx);
     else
-        build_records_block<true>(g, alpha_limit, order, idx, s_rec, s_opt);
+        build_records_block(g, alpha_limit, order, idx, s_rec);
 }
 
-void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, int order, bool with_optics) {
+void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, int order) {
     if (g.n_cells <= 0) return;
     const unsigned blocks = static_cast<unsigned>((g.n_cells + 255) / 256);
-    if (with_optics)
-        hipLaunchKernelGGL(build_records<true>, dim3(blocks), dim3(256), 0, s, g, alpha_limit, order);
-    else
-        hipLaunchKernelGGL(build_records<false>, dim3(blocks), dim3(256), 0, s, g, alpha_limit, order);
+    hipLaunchKernelGGL(build_records, dim3(blocks), dim3(256), 0, s, g, alpha_limit, order);
 }
 
 void launch_entry_lists(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
@@ -152,19 +127,14 @@ __device__ __forceinline__ double reference_emission_step(double I, double alpha
     return (q - C * e) * inv_alpha;
 }
 
-// Geometry of one step: where the ray (x, y) crosses the current cell and through which face it
-// leaves.  Slots 0..n_up-1 of the record are upper faces, the rest lower (device_types.hpp).
+// Geometry of one step: how far along the walk the ray (x, y) leaves the current cell, and through which face.
+// The record holds the (up to three) faces a ray can leave through as planes of the walk coordinate w about the
+// absolute pixel coordinates (device_types.hpp: ExitRecord); the chord is w_exit minus the depth at which the ray
+// entered — the exit depth of the cell before, or the boundary entry's own depth (the caller's `carry`).
 struct StepGeometry {
-    double dz;         // z_top - z_bot (line.cpp:124-131)
-    double s_exit;     // position of the exit face along the walk (z walking down, -z walking up)
+    double w_exit;     // min over the candidates; +inf: the ray cannot leave (flat cell, edge-on faces): it ends here
     uint32_t w_out;    // neighbour word of the exit face
-    bool contributes;  // the ray really crosses the cell
-    bool has_exit;
 };
-
-struct CellRegs;
-template <bool kUp>
-__device__ __forceinline__ StepGeometry step_geometry(const CellRegs& cur, double x, double y);
 
 // ORDER 0: walk from -z to +z and integrate back to front exactly like
 //          line::integrate_ray_value_by_i (the reference sorts by z_hi descending and runs the
@@ -175,18 +145,16 @@ __device__ __forceinline__ StepGeometry step_geometry(const CellRegs& cur, doubl
 //          recurrence is itself well conditioned.
 //
 // Structure of a step (one cell of one ray): the record of the current cell is already in
-// registers; the four face planes give the exit face and therefore the next cell; the loads of
+// registers; its three candidate planes give the exit face and therefore the next cell; the loads of
 // the NEXT cell's record are issued right there, and the exp/divide work of the CURRENT cell runs
 // while they are in flight.  Face selection is branch-free (selects), so a step has two
 // data-dependent branches only: "this cell contributes" and "the ray left the grid".
 struct CellRegs {
-    D2 r0, r1, r2, r3, r4, r5, r6, r7;  // CellRecord
-    D2 o0, o1;                          // CellOptics
+    D2 r0, r1, r2, r3, r4, r5, r6, r7;  // ExitRecord: r0-r4 planes (+ nbr[0..1] in r4.b), r5.a = nbr[2] | flags, r6 / r7 optics
 };
 
-__device__ __forceinline__ void load_cell(CellRegs& c, const CellRecord* rec, const CellOptics* opt, int cell) {
+__device__ __forceinline__ void load_cell(CellRegs& c, const ExitRecord* rec, int cell) {
     const D2* rp = reinterpret_cast<const D2*>(rec + cell);
-    const D2* op = reinterpret_cast<const D2*>(opt + cell);
     c.r0 = rp[0];
     c.r1 = rp[1];
     c.r2 = rp[2];
@@ -195,40 +163,27 @@ __device__ __forceinline__ void load_cell(CellRegs& c, const CellRecord* rec, co
     c.r5 = rp[5];
     c.r6 = rp[6];
     c.r7 = rp[7];
-    c.o0 = op[0];
-    c.o1 = op[1];
 }
 
-template <bool kUp>
+// min as ONE instruction (fmin() on a value the compiler cannot prove canonical is preceded by a canonicalising
+// v_max_f64 x, x; the operands here are never NaN: a candidate is a finite depth or +inf)
+__device__ __forceinline__ double min_f64(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ StepGeometry step_geometry(const CellRegs& cur, double x, double y) {
-    const double dx = x - cur.r0.a, dy = y - cur.r0.b;
-    // plane k = (c, gx, gy): r1.a r1.b r2.a | r2.b r3.a r3.b | r4.a r4.b r5.a | r5.b r6.a r6.b
-    const double z0 = fma(cur.r1.b, dx, fma(cur.r2.a, dy, cur.r1.a));
-    const double z1 = fma(cur.r3.a, dx, fma(cur.r3.b, dy, cur.r2.b));
-    const double z2 = fma(cur.r4.b, dx, fma(cur.r5.a, dy, cur.r4.a));
-    const double z3 = fma(cur.r6.a, dx, fma(cur.r6.b, dy, cur.r5.b));
-    const unsigned long long w01 = __double_as_longlong(cur.r7.a);
-    const unsigned long long w23 = __double_as_longlong(cur.r7.b);
-    const uint32_t w0 = static_cast<uint32_t>(w01), w1 = static_cast<uint32_t>(w01 >> 32);
-    const uint32_t w2 = static_cast<uint32_t>(w23), w3 = static_cast<uint32_t>(w23 >> 32);
-    const uint32_t n_up = w0 >> kUpperCountShift;  // 1..3: slot 0 is always upper, slot 3 always lower
-    const bool up1 = n_up > 1u, up2 = n_up > 2u;
-    const double u1 = up1 ? z1 : INFINITY, l1 = up1 ? -INFINITY : z1;
-    const double u2 = up2 ? z2 : INFINITY, l2 = up2 ? -INFINITY : z2;
-    const double z_top = fmin(z0, fmin(u1, u2));
-    const double z_bot = fmax(z3, fmax(l1, l2));
+    // plane k = (c, gx, gy): r0.a r0.b r1.a | r1.b r2.a r2.b | r3.a r3.b r4.a
+    const double w0 = fma(cur.r0.b, x, fma(cur.r1.a, y, cur.r0.a));
+    const double w1 = fma(cur.r2.a, x, fma(cur.r2.b, y, cur.r1.b));
+    const double w2 = fma(cur.r3.b, x, fma(cur.r4.a, y, cur.r3.a));
+    const unsigned long long n01 = __double_as_longlong(cur.r4.b);
+    const uint32_t n0 = static_cast<uint32_t>(n01), n1 = static_cast<uint32_t>(n01 >> 32);
+    const uint32_t n2 = static_cast<uint32_t>(__double_as_longlong(cur.r5.a));
     StepGeometry g;
-    g.dz = z_top - z_bot;
-    g.contributes = g.dz > 0.0 && g.dz < INFINITY;
-    if (kUp) {  // leaves through the lowest upper face
-        g.w_out = (z0 == z_top) ? w0 : (u1 == z_top) ? w1 : w2;
-        g.has_exit = z_top < INFINITY;
-        g.s_exit = -z_top;
-    } else {    // leaves through the highest lower face
-        g.w_out = (z3 == z_bot) ? w3 : (l2 == z_bot) ? w2 : w1;
-        g.has_exit = z_bot > -INFINITY;
-        g.s_exit = z_bot;
-    }
+    g.w_exit = min_f64(w0, min_f64(w1, w2));
+    g.w_out = (w0 == g.w_exit) ? n0 : (w1 == g.w_exit) ? n1 : n2;
     return g;
 }
 
@@ -269,7 +224,7 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
 
     unsigned n_seg = 0, n_step = 0, is_solid = 0, overflow = 0;
     double tau = 0.0, I = 0.0, T = 1.0;
-    double x = 0.0, y = 0.0, s_cur = DBL_MAX;
+    double x = 0.0, y = 0.0, w_cur = -DBL_MAX, carry = 0.0;  // carry: the depth (walk coordinate) at which the ray entered the current cell
     EntryHead ent{0, 0};
     int cell = -1;
     size_t lp = 0;
@@ -291,21 +246,26 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
             y = P.Ytab[global_row_of(im, lrow)];
             // touched once per frame: keep them from displacing the cell records in L2 / Infinity Cache
             ent = load_entry_head(P.entry_head + lp);
-            if (ent.count > 0) cell = next_entry<kUp>(P, lp, ent, s_cur);
+            if (ent.count > 0) cell = next_entry<kUp>(P, lp, ent, w_cur, carry);
         }
     }
 
     CellRegs cur;
-    if (cell >= 0) load_cell(cur, P.rec, P.opt, cell);
+    if (cell >= 0) load_cell(cur, P.xrec, cell);
 
     while (cell >= 0) {
-        const StepGeometry sg = step_geometry<kUp>(cur, x, y);
+        const StepGeometry sg = step_geometry(cur, x, y);
         ++n_step;
+        const bool has_exit = sg.w_exit < INFINITY;
+        const double dz = sg.w_exit - carry;  // line.cpp:124-131: the chord through the cell
+        const bool contributes = dz > 0.0 && dz < INFINITY;
 
         // where next?
         int nb = -1;
-        if (sg.has_exit) {
-            s_cur = fmin(s_cur, sg.s_exit);
+        double carry_next = carry;
+        if (has_exit) {
+            carry_next = sg.w_exit;
+            w_cur = fmax(w_cur, sg.w_exit);
             const uint32_t id = sg.w_out & kIdMask;
             if (id != kNoCell) nb = static_cast<int>(id);
         }
@@ -313,27 +273,28 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
             overflow = 1;
             nb = -1;
         } else if (nb < 0 && !overflow) {
-            nb = next_entry<kUp>(P, lp, ent, s_cur);  // left the grid: re-entry of a non-convex grid?
+            nb = next_entry<kUp>(P, lp, ent, w_cur, carry_next);  // left the grid: re-entry of a non-convex grid?
         }
 
         // issue the next cell's loads now; the arithmetic below does not depend on them
         CellRegs nxt;
-        if (nb >= 0) load_cell(nxt, P.rec, P.opt, nb);
+        if (nb >= 0) load_cell(nxt, P.xrec, nb);
 
-        if (sg.contributes) {
+        if (contributes) {
             ++n_seg;
-            tau = fma(sg.dz, cur.o0.a, tau);  // line.cpp:189 (unclamped alpha)
+            tau = fma(dz, cur.r6.a, tau);  // line.cpp:189 (unclamped alpha)
             if (ORDER == 0) {
                 // line.cpp:220-224 (NaN alpha propagates like there)
-                if (cur.o0.b != 0.0) I = reference_emission_step(I, cur.o0.b, cur.o1.b, cur.o1.a, sg.dz);
+                if (cur.r6.b != 0.0) I = reference_emission_step(I, cur.r6.b, cur.r7.b, cur.r7.a, dz);
             } else if (T >= P.t_cutoff) {
                 // I = sum_k T_k (Q/alpha)(1 - e^{-alpha dz}); T_{k+1} = T_k e^{-alpha dz}
-                const double ex = exp_nonpositive(-cur.o0.b * sg.dz);
-                I = fma(T * cur.o1.a, 1.0 - ex, I);
+                const double ex = exp_nonpositive(-cur.r6.b * dz);
+                I = fma(T * cur.r7.a, 1.0 - ex, I);
                 T *= ex;
             }
         }
         cell = nb;
+        carry = carry_next;
         cur = nxt;
     }
 
@@ -381,13 +342,11 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
 // walk_composite_lds: the same walk with the current cells staged through LDS.
 //
 // Neighbouring pixels of a row tile are mostly inside the same cell, so per step a wavefront
-// needs only a handful of distinct 160-byte records, not 64.  The direct kernel still issues
-// ten 16-byte loads per lane and step and is bound by the CU's vector-memory address path
-// (rocprofv3: 2.9e7 VMEM wave-instructions per frame).  Here the wavefront
-//   1. finds the runs of equal next-cell ids along its lanes (compare with the lane to the left,
-//      ballot, popcount -> slot per run),
-//   2. loads each run's record ONCE, cooperatively: 8 lanes x 16 B per CellRecord, 2 lanes x 16 B
-//      per CellOptics (coalesced 128-byte and 32-byte segments),
+// needs only a handful of distinct 128-byte records, not 64.  The direct kernel still issues
+// eight 16-byte loads per lane and step and is bound by the CU's vector-memory address path.
+// Here the wavefront
+//   1. gives every DISTINCT next-cell id among its lanes a slot (leader election, below),
+//   2. loads each slot's record ONCE, cooperatively: 8 lanes x 16 B per ExitRecord (one 128-byte line),
 //   3. parks the pieces in a wave-private LDS area (144-byte stride: conflict-free b128 reads),
 //   4. and every lane reads its own cell's record from LDS (lanes of a run broadcast).
 // The global loads of step k+1 are issued as soon as the exit face of step k is known and are in
@@ -401,7 +360,7 @@ constexpr bool kElectLeaders = C5_ELECT_LEADERS != 0;  // 0: slots per run of eq
 // per SIMD 0.663 ms; 32 slots 0.753 (LDS then caps the CU at 5 workgroups); 8 slots 0.735 (direct-load
 // fallback too often); 7 wavefronts per SIMD (72 VGPRs, 14 spilled) 0.662.
 #ifndef C5_STAGE_SLOTS
-#define C5_STAGE_SLOTS 16
+#define C5_STAGE_SLOTS 14
 #endif
 #ifndef C5_WALK_WAVES
 #define C5_WALK_WAVES 6
@@ -411,74 +370,17 @@ constexpr int kStageSlots = C5_STAGE_SLOTS;
 #define C5_ELECT_BUCKETS 256
 #endif
 constexpr unsigned kBuckets1 = C5_ELECT_BUCKETS;  // first leader table (power of two)   // runs of equal cell ids staged per wavefront and step (more: direct loads)
-// One staged cell in LDS, 16-byte units: 8 of CellRecord, 2 of CellOptics, no pad.  160 bytes = 40 banks: eight
-// consecutive slots start on eight different 16-byte bank columns (slots s and s + 8 share theirs).  With a pad
-// unit (176 bytes: sixteen different columns, no conflict at all) a DMA pass stages five slots instead of six:
-// measured, the sixth slot is worth more than the missing conflicts cost (C3 frame 0.557 -> 0.549 ms, 1200 x 900
-// 0.326 -> 0.318).
+// One staged cell in LDS, 16-byte units: the 8 of its ExitRecord + 1 pad.  144 bytes = 36 banks: sixteen consecutive
+// slots start on sixteen different 4-bank columns (slots s and s + 16 share theirs), so the lanes of a 16-lane group
+// read their cells without bank conflicts; a DMA pass (64 lanes, destinations lane-linear) stages seven whole slots,
+// its pad lanes idle.  (A stride of 8 units would let a pass stage eight, at the price of two-way conflicts between
+// slots of equal parity.)
 #ifndef C5_SLOT_STRIDE
-#define C5_SLOT_STRIDE 10
+#define C5_SLOT_STRIDE 9
 #endif
 constexpr int kSlotStride = C5_SLOT_STRIDE;
 using V2 = double __attribute__((ext_vector_type(2)));  // 16 bytes as one SSA value (never an alloca)
 __device__ __forceinline__ D2 as_d2(V2 v) { return D2{v.x, v.y}; }
-
-// min / max as ONE instruction.  fmin()/fmax() on a value the compiler cannot prove canonical (one
-// that went through integer selects) is preceded by a canonicalising v_max_f64 x, x; the operands
-// here are never signalling NaNs, and a quiet NaN operand is ignored (IEEE minNum / maxNum), which
-// step_geometry_fast uses on purpose.
-__device__ __forceinline__ double min_f64(double a, double b) {
-    double r;
-    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ double max_f64(double a, double b) {
-    double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-// step_geometry with the slot classification done on the HIGH WORD only: a slot that is not an upper
-// face takes part in the min as a quiet NaN (high word 0x7FF80000, low word left as it is), which
-// v_min_f64 ignores and no comparison ever equals — one v_cndmask per candidate instead of a 64-bit
-// select against +-inf.  Slots 0 (always upper) and 3 (always lower) are real numbers or +-inf, so
-// z_top and z_bot are never NaN.  Same results as step_geometry, bit for bit.
-template <bool kUp>
-__device__ __forceinline__ StepGeometry step_geometry_fast(const CellRegs& cur, double x, double y) {
-    const double dx = x - cur.r0.a, dy = y - cur.r0.b;
-    const double z0 = fma(cur.r1.b, dx, fma(cur.r2.a, dy, cur.r1.a));
-    const double z1 = fma(cur.r3.a, dx, fma(cur.r3.b, dy, cur.r2.b));
-    const double z2 = fma(cur.r4.b, dx, fma(cur.r5.a, dy, cur.r4.a));
-    const double z3 = fma(cur.r6.a, dx, fma(cur.r6.b, dy, cur.r5.b));
-    const unsigned long long w01 = __double_as_longlong(cur.r7.a);
-    const unsigned long long w23 = __double_as_longlong(cur.r7.b);
-    const uint32_t w0 = static_cast<uint32_t>(w01), w1 = static_cast<uint32_t>(w01 >> 32);
-    const uint32_t w2 = static_cast<uint32_t>(w23), w3 = static_cast<uint32_t>(w23 >> 32);
-    const uint32_t n_up = w0 >> kUpperCountShift;  // 1..3
-    const bool up1 = n_up > 1u, up2 = n_up > 2u;
-    constexpr int kQuietNan = 0x7FF80000;
-    const int z1h = __double2hiint(z1), z1l = __double2loint(z1);
-    const int z2h = __double2hiint(z2), z2l = __double2loint(z2);
-    const double u1 = __hiloint2double(up1 ? z1h : kQuietNan, z1l);
-    const double l1 = __hiloint2double(up1 ? kQuietNan : z1h, z1l);
-    const double u2 = __hiloint2double(up2 ? z2h : kQuietNan, z2l);
-    const double l2 = __hiloint2double(up2 ? kQuietNan : z2h, z2l);
-    const double z_top = min_f64(z0, min_f64(u1, u2));
-    const double z_bot = max_f64(z3, max_f64(l1, l2));
-    StepGeometry g;
-    g.dz = z_top - z_bot;
-    g.contributes = g.dz > 0.0 && g.dz < INFINITY;
-    if (kUp) {
-        g.w_out = (z0 == z_top) ? w0 : (u1 == z_top) ? w1 : w2;
-        g.has_exit = z_top < INFINITY;
-        g.s_exit = -z_top;
-    } else {
-        g.w_out = (z3 == z_bot) ? w3 : (l2 == z_bot) ? w2 : w1;
-        g.has_exit = z_bot > -INFINITY;
-        g.s_exit = z_bot;
-    }
-    return g;
-}
 
 // Optional in-kernel phase clock (build with -DC5_WALK_STAMPS=1; scripts/stamp_walk.py): ONE WAVEFRONT IN 64 sums, per
 // phase of a step, the shader cycles between stamps (s_memtime; tick = shader cycle) and lane 0 adds them to
@@ -511,12 +413,9 @@ __device__ unsigned long long g_walk_trace[4 * 131072];
 // DMA = true (option "lds_stage" 2): the staging loads write LDS themselves (global_load_lds_dwordx4: destination =
 // wave-uniform base + 16 * lane, no vector register in between, no ds_write_b128 — a 16-byte LDS store costs 13
 // LDS cycles per wave-instruction, a step's three as much as its ten reads).  A pass of 64 lanes fills 64
-// consecutive 16-byte units of the wavefront's staging area, i.e. units 64 j ... 64 j + 63 of the same
-// slot * 11 + piece image the register path writes: lane -> (slot, piece) differs from pass to pass (11 does not
-// divide 64), so every lane keeps, per pass, where its slot's cell id is posted and what its piece's source
-// offset is; pad units and slots beyond the staged ones are masked off.  Records and optics are fetched by the
-// SAME instruction (pieces 0-7: rec + id * 128, pieces 8-9: opt + id * 32): the host allocates opt behind rec, so
-// that one 32-bit offset from rec reaches both.
+// consecutive 16-byte units of the wavefront's staging area: seven whole slots of nine units (eight pieces of the
+// cell's one 128-byte line + a pad unit whose lane idles), the same (slot within the pass, piece) for a lane in
+// every pass, so three registers describe its part: where that slot's cell id is posted, and the piece's offset.
 #ifndef C5_DMA_WAVES
 #define C5_DMA_WAVES 7
 #endif
@@ -526,12 +425,11 @@ __device__ unsigned long long g_walk_trace[4 * 131072];
 #define C5_EMIT_NOW 0
 #endif
 using LdsInts = const __attribute__((address_space(3))) int*;
-// SLOTS: distinct cells staged per wavefront and step (16, or 24 for frames whose pixels are coarse against the
-// cells: more distinct cells per 8x8 tile; 24 slots leave a CU six workgroups instead of seven).  Walk ms with
-// 16 / 24 slots: C3 grid at 1200x900 0.318 / 0.271, C2 ball 0.119 / 0.114, C3 at 2400x1800 0.549 / 0.574, at
-// 4800x3600 1.84 / 1.99 — the host picks by the rays per cell of the frame before (c_api.hip).
+// SLOTS: distinct cells staged per wavefront and step: 14 (two DMA passes of seven), or 21 (three) for frames whose
+// pixels are coarse against the cells: more distinct cells per 8x8 tile — the host picks by the rays per cell of the
+// frame before (c_api.hip).
 template <int TILE, int ORDER, bool DMA = false, int SLOTS = kStageSlots>
-__global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 6 : C5_DMA_WAVES) : C5_WALK_WAVES) void walk_composite_lds(WalkParams P) {
+__global__ __launch_bounds__(256, DMA ? C5_DMA_WAVES : C5_WALK_WAVES) void walk_composite_lds(WalkParams P) {
     constexpr int kStageSlots = SLOTS;  // (shadows the namespace constant: everything below is per instantiation)
     using TS = TileShape<TILE>;
     constexpr int TW = TS::WW * TS::GX, TH = TS::WH * TS::GY;
@@ -595,14 +493,14 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 6 : C5_DMA_WAVES) : C5_WAL
     // records and optics are addressed as a uniform base + a 32-bit byte offset per lane (the host
     // only picks this kernel while n_cells * 128 fits 32 bits): one shift-or per load instead of a
     // 64-bit shift and a 64-bit add
-    const char* const rec_bytes = reinterpret_cast<const char*>(P.rec);
-    const char* const opt_bytes = reinterpret_cast<const char*>(P.opt);
+    const char* const rec_bytes = reinterpret_cast<const char*>(P.xrec);
 
     constexpr unsigned kOverflowBit = 0x80000000u;  // of n_seg: the ray hit the step bound
     unsigned n_seg = 0;
     unsigned n_step_wave = 0;  // wave-uniform: lane-steps taken by the whole wavefront
     double tau = 0.0, I = 0.0, T = 1.0;
     double x = 0.0, y = 0.0;
+    double carry = 0.0;  // the depth (walk coordinate) at which the ray entered the cell it is about to cross
     int nb = -1;
 
     {
@@ -628,9 +526,9 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 6 : C5_DMA_WAVES) : C5_WAL
         if (in_image && !mv) {  // (a solid-marked pixel is written at the end, without a walk)
             x = P.Xtab[pixel_col()];
             y = P.Ytab[global_row_of(im, pixel_lrow())];
-            double s_cur = DBL_MAX;
-            if (ent.count > 0) nb = next_entry<kUp>(P, lp, ent, s_cur);
-            my_scur[lane] = s_cur;
+            double w_cur = -DBL_MAX;
+            if (ent.count > 0) nb = next_entry<kUp>(P, lp, ent, w_cur, carry);
+            my_scur[lane] = w_cur;
         }
     }
     my_elect[kBuckets1 + 64 + lane] = 0;  // slot ids: always a valid cell id, whatever the slot's state
@@ -642,31 +540,27 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 6 : C5_DMA_WAVES) : C5_WAL
     V2 pend_o0 = {0.0, 0.0}, pend_o1 = {0.0, 0.0};
 
     // lane-constant pieces of the staging addresses
-    static_assert(kStageSlots % 8 == 0 && kStageSlots <= 32, "whole passes of 8 slots, one optics pass");
-    constexpr int kPasses = kStageSlots / 8;
-    const int piece = lane & 7, sub = lane >> 3, so = lane >> 1;
+    static_assert(kStageSlots <= 32, "slot ids live in 64 ints; the register path stages passes of 8 slots");
+    constexpr int kPasses = (kStageSlots + 7) / 8;  // register path: 8 slots (8 lanes x 16 B each) per pass
+    const int piece = lane & 7, sub = lane >> 3;
     const uint32_t rec_piece_off = static_cast<uint32_t>(piece) * 16u;
-    const uint32_t opt_piece_off = static_cast<uint32_t>(lane & 1) * 16u;
-    const int sub4 = sub << 2, so4 = so << 2;  // ds_bpermute byte addresses of slot `sub` / `so`
+    const int sub4 = sub << 2;  // ds_bpermute byte address of slot `sub`
     V2* const put_rec = my_stage + sub * kSlotStride + piece;         // + 8 * pass * kSlotStride
-    V2* const put_opt = my_stage + so * kSlotStride + 8 + (lane & 1);
-    // DMA: a pass stages kDmaSlots = 6 whole slots (60 lanes; the last four idle), so that a lane fetches the same
-    // piece of the same slot-within-the-pass in every pass: three registers hold where that slot's cell id is
-    // posted, log2 of the bytes per cell of the array the piece comes from and the piece's offset from P.rec.
-    // Pass j: slots 6 j ... 6 j + 5, LDS units from 60 j.
+    // DMA: a pass stages kDmaSlots = 7 whole slots (63 lanes, of which the seven pad lanes and lane 63 idle), so that a
+    // lane fetches the same piece of the same slot-within-the-pass in every pass: two registers hold where that
+    // slot's cell id is posted and the piece's offset inside the cell's 128-byte line.
+    // Pass j: slots 7 j ... 7 j + 6, LDS units from 63 j.
     constexpr int kDmaSlots = 64 / kSlotStride;
     constexpr int kDmaPasses = (kStageSlots + kDmaSlots - 1) / kDmaSlots;
-    uint32_t dma_id_at = 0, dma_pitch = 0, dma_off = 0;
+    uint32_t dma_id_at = 0, dma_off = 0;
     if (DMA) {
-        const uint32_t opt_delta = static_cast<uint32_t>(opt_bytes - rec_bytes);
         const uint32_t ids_at = (uint32_t)(uintptr_t)(LdsInts)(my_elect + kBuckets1 + 64);  // LDS byte address
         const int s_ = lane / kSlotStride, pc = lane - s_ * kSlotStride;
-        const bool has = s_ < kDmaSlots && pc < 10;
+        const bool has = s_ < kDmaSlots && pc < 8;
         // (idle lanes: a slot no pass ever stages — still an address inside the workgroup's LDS, so that the id reads
         // below need no predicate and are all in flight before the first load is issued)
         dma_id_at = ids_at + 4u * static_cast<uint32_t>(has ? s_ : 60);
-        dma_pitch = pc < 8 ? 7u : 5u;
-        dma_off = pc < 8 ? 16u * static_cast<uint32_t>(pc) : opt_delta + 16u * static_cast<uint32_t>(pc - 8);
+        dma_off = 16u * static_cast<uint32_t>(pc & 7);
     }
 
     // A lane steps in every iteration from its start to its end (re-entry takes no extra iteration), so
@@ -778,7 +672,6 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 6 : C5_DMA_WAVES) : C5_WAL
 #pragma clang diagnostic ignored "-Wsometimes-uninitialized"
 #pragma clang diagnostic ignored "-Wconditional-uninitialized"
         V2 stage_r[kPasses];  // a skipped pass leaves its register undefined; it is never stored either
-        V2 stage_o0;
 #pragma clang diagnostic pop
         if (DMA) {
             const uint32_t ids_end = (uint32_t)(uintptr_t)(LdsInts)(my_elect + kBuckets1 + 64) + 4u * static_cast<uint32_t>(n_staged);
@@ -789,7 +682,7 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 6 : C5_DMA_WAVES) : C5_WAL
             for (int j = 0; j < kDmaPasses; ++j) {
                 if (j == 0 || kDmaSlots * j < n_staged) {  // wave-uniform: does the pass reach a staged slot at all
                     if (dma_id_at < ids_end - 4u * kDmaSlots * j) {  // this lane's slot kDmaSlots j + s is staged (idle lanes: never)
-                        const uint32_t off = (id_of_pass[j] << dma_pitch) + dma_off;
+                        const uint32_t off = (id_of_pass[j] << 7) + dma_off;
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rec_bytes + off),
                                                          (__attribute__((address_space(3))) void*)(my_stage + kDmaSlots * kSlotStride * j), 16, 0, 0);
                     }
@@ -804,8 +697,6 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 6 : C5_DMA_WAVES) : C5_WAL
                     stage_r[pass] = *reinterpret_cast<const V2*>(rec_bytes + ((id_ << 7) | rec_piece_off));
                 }
             }
-            const uint32_t ido = static_cast<uint32_t>(kElectLeaders ? my_elect[kBuckets1 + 64 + so] : __builtin_amdgcn_ds_bpermute(so4, id_of_lane));
-            stage_o0 = *reinterpret_cast<const V2*>(opt_bytes + ((ido << 5) | opt_piece_off));
         }
         C5_STAMP(1);  // bpermutes landed, five loads issued
 
@@ -838,7 +729,6 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 6 : C5_DMA_WAVES) : C5_WAL
 #pragma unroll
             for (int pass = 0; pass < kPasses; ++pass)
                 if (sub < n_staged - 8 * pass) put_rec[8 * pass * kSlotStride] = stage_r[pass];
-            if (so < n_staged) *put_opt = stage_o0;
         }
         __builtin_amdgcn_wave_barrier();
 #if C5_WALK_STAMPS
@@ -846,7 +736,8 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 6 : C5_DMA_WAVES) : C5_WAL
         C5_STAMP(3);  // loads landed, pieces parked in LDS
 #endif
 
-        // 4. every ray fetches its cell
+        // 4. every ray fetches its cell: eight 16-byte reads (the planes it can leave through, the neighbours behind
+        //    them, the optics)
         if (need) {
             CellRegs cur;
             const V2* r = reinterpret_cast<const V2*>(reinterpret_cast<const char*>(my_stage) +
@@ -859,45 +750,46 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 6 : C5_DMA_WAVES) : C5_WAL
                 cur.r3 = as_d2(r[3]);
                 cur.r4 = as_d2(r[4]);
                 cur.r5 = as_d2(r[5]);
-                cur.r6 = as_d2(r[6]);
-                cur.r7 = as_d2(r[7]);
                 // the optics ride along, straight into the pending registers: those are free here (the
                 // previous step's emission is done) and only looked at again if this step contributes
-                pend_o0 = r[8];
-                pend_o1 = r[9];
+                pend_o0 = r[6];
+                pend_o1 = r[7];
             } else {
-                load_cell(cur, P.rec, P.opt, nb);  // more distinct cells than slots: rare
-                pend_o0 = V2{cur.o0.a, cur.o0.b};
-                pend_o1 = V2{cur.o1.a, cur.o1.b};
+                load_cell(cur, P.xrec, nb);  // more distinct cells than slots: rare
+                pend_o0 = V2{cur.r6.a, cur.r6.b};
+                pend_o1 = V2{cur.r7.a, cur.r7.b};
             }
 
-            const StepGeometry sg = step_geometry_fast<kUp>(cur, x, y);
-            if (sg.contributes) {
+            const StepGeometry sg = step_geometry(cur, x, y);
+            const double dz = sg.w_exit - carry;  // line.cpp:124-131: the chord through the cell
+            if (dz > 0.0 && dz < INFINITY) {
                 ++n_seg;
-                tau = fma(sg.dz, pend_o0.x, tau);  // line.cpp:189 (unclamped alpha); order-independent, done now
+                tau = fma(dz, pend_o0.x, tau);  // line.cpp:189 (unclamped alpha); order-independent, done now
                 if (kEmitNow) {
                     if (ORDER == 0) {
-                        if (pend_o0.y != 0.0) I = reference_emission_step<false>(I, pend_o0.y, pend_o1.y, pend_o1.x, sg.dz);
+                        if (pend_o0.y != 0.0) I = reference_emission_step<false>(I, pend_o0.y, pend_o1.y, pend_o1.x, dz);
                     } else if (T >= P.t_cutoff) {
-                        const double ex = exp_nonpositive(-pend_o0.y * sg.dz);
+                        const double ex = exp_nonpositive(-pend_o0.y * dz);
                         I = fma(T * pend_o1.x, 1.0 - ex, I);
                         T *= ex;
                     }
                 } else {
                     pend = true;
-                    pend_dz = sg.dz;
+                    pend_dz = dz;
                 }
             }
-            // an edge-on or flat slot forwards nothing (build_records), so the neighbour word alone
-            // says whether the ray goes on inside the grid
+            // the ray enters the next cell where it leaves this one (a cell it cannot leave — flat, or all its
+            // candidates edge-on — has w_exit = +inf and no neighbour: the ray ends there, as before)
+            const bool has_exit = sg.w_exit < INFINITY;
+            if (has_exit) carry = sg.w_exit;
             const uint32_t id = sg.w_out & kIdMask;
             int nxt = static_cast<int>(id);
             if (id == kNoCell) {  // left the grid: re-entry of a non-convex grid?
                 const size_t lp = pixel_index();
-                double s_cur = my_scur[lane];
-                if (sg.has_exit) s_cur = fmin(s_cur, sg.s_exit);
-                nxt = next_entry<kUp>(P, lp, load_entry_head(P.entry_head + lp), s_cur);
-                my_scur[lane] = s_cur;
+                double w_cur = my_scur[lane];
+                if (has_exit) w_cur = fmax(w_cur, sg.w_exit);
+                nxt = next_entry<kUp>(P, lp, load_entry_head(P.entry_head + lp), w_cur, carry);
+                my_scur[lane] = w_cur;
             }
             nb = nxt;
         }
@@ -1032,7 +924,7 @@ static void launch_walk_t(hipStream_t s, const WalkParams& p) {
         WalkParams q = p;
         q.band_tiles = S;
         if (p.lds_stage == 2 && p.stage_slots > 16)
-            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true, 24>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, q);
+            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true, 21>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, q);
         else if (p.lds_stage == 2)
             hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, q);
         else
@@ -1051,7 +943,7 @@ static void launch_walk_t(hipStream_t s, const WalkParams& p) {
         WalkParams q = p;
         q.band_tiles = band;
         if (p.lds_stage == 2 && p.stage_slots > 16)
-            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true, 24>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, q);
+            hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true, 21>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, q);
         else if (p.lds_stage == 2)
             hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, q);
         else if (p.lds_stage)
@@ -1061,7 +953,7 @@ static void launch_walk_t(hipStream_t s, const WalkParams& p) {
         return;
     }
     if (p.lds_stage == 2 && p.stage_slots > 16)
-        hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true, 24>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, p);
+        hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true, 21>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, p);
     else if (p.lds_stage == 2)
         hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, p);
     else if (p.lds_stage)

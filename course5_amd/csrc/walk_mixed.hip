@@ -225,9 +225,9 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) void w
         }
         if (in_image && !mv) {
             grow = global_row_of(im, lrow);
-            double s_cur = DBL_MAX;
-            if (ent.count > 0) nb = next_entry<kUp>(P, lp, ent, s_cur);
-            my_scur[lane] = s_cur;
+            double w_cur = -DBL_MAX, w_entry = 0.0;  // (this walk evaluates both faces of a cell itself: the entry's depth is not used)
+            if (ent.count > 0) nb = next_entry<kUp>(P, lp, ent, w_cur, w_entry);
+            my_scur[lane] = w_cur;
         }
     }
     my_elect[kMixBuckets + 64 + lane] = 0;  // slot ids: always a valid cell id
@@ -441,13 +441,13 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) void w
             int nxt = static_cast<int>(id);
             if (id == kNoCell) {  // left the grid: re-entry of a non-convex grid?
                 const size_t lp = pixel_index();
-                double s_cur = my_scur[lane];
+                double w_cur = my_scur[lane], w_entry = 0.0;
                 if (has_exit) {
                     const double z_abs = static_cast<double>(P.z0[nb]) + static_cast<double>(z_exit);
-                    s_cur = fmin(s_cur, kUp ? -z_abs : z_abs);
+                    w_cur = fmax(w_cur, kUp ? z_abs : -z_abs);  // walk coordinate: grows along the walk
                 }
-                nxt = next_entry<kUp>(P, lp, load_entry_head(P.entry_head + lp), s_cur);
-                my_scur[lane] = s_cur;
+                nxt = next_entry<kUp>(P, lp, load_entry_head(P.entry_head + lp), w_cur, w_entry);
+                my_scur[lane] = w_cur;
             }
             nb = nxt;
         }
