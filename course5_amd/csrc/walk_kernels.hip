@@ -416,20 +416,26 @@ __device__ unsigned long long g_walk_trace[4 * 131072];
 // consecutive 16-byte units of the wavefront's staging area: seven whole slots of nine units (eight pieces of the
 // cell's one 128-byte line + a pad unit whose lane idles), the same (slot within the pass, piece) for a lane in
 // every pass, so three registers describe its part: where that slot's cell id is posted, and the piece's offset.
+// Wavefronts per SIMD of the LDS-DMA kernel: 8 (62 VGPRs with the emission integrated at once, below).  Measured on the
+// exit-record kernel (C3 frame / C3 at 4800x3600 / C2 ball, walk ms): 7 wavefronts with the emission deferred into
+// the next step's load shadow 0.4942 / 1.671 / 0.0965; emission at once, 7 wavefronts 0.4954 / 1.678 / 0.0956;
+// emission at once, 8 wavefronts 0.4786 / 1.618 / 0.0944; deferred, 8 wavefronts (64 VGPRs, 12 B of scratch)
+// 0.4832 / 1.622 / 0.1043.  (On the four-plane records of rounds 1-2 an eighth wavefront bought nothing: the vector
+// issue was full at seven; the exit records issue a fifth fewer vector instructions per step.)
 #ifndef C5_DMA_WAVES
-#define C5_DMA_WAVES 7
+#define C5_DMA_WAVES 8
 #endif
 // 1 (DMA kernel only): a step's emission/absorption is integrated at once, behind its geometry — nothing carried to
 // the next iteration, ten registers fewer — instead of in the shadow of the next step's loads
 #ifndef C5_EMIT_NOW
-#define C5_EMIT_NOW 0
+#define C5_EMIT_NOW 1
 #endif
 using LdsInts = const __attribute__((address_space(3))) int*;
 // SLOTS: distinct cells staged per wavefront and step: 14 (two DMA passes of seven), or 21 (three) for frames whose
 // pixels are coarse against the cells: more distinct cells per 8x8 tile — the host picks by the rays per cell of the
 // frame before (c_api.hip).
 template <int TILE, int ORDER, bool DMA = false, int SLOTS = kStageSlots>
-__global__ __launch_bounds__(256, DMA ? C5_DMA_WAVES : C5_WALK_WAVES) void walk_composite_lds(WalkParams P) {
+__global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WALK_WAVES) void walk_composite_lds(WalkParams P) {
     constexpr int kStageSlots = SLOTS;  // (shadows the namespace constant: everything below is per instantiation)
     using TS = TileShape<TILE>;
     constexpr int TW = TS::WW * TS::GX, TH = TS::WH * TS::GY;
