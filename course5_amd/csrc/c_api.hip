@@ -138,6 +138,8 @@ struct c5_context {
     int solid_cache = 1;    // a solid unchanged since the frame before is not rastered again (enqueue_solids)
     int overlap_setup = 0;  // measured: 1.27 vs 1.26 ms/frame, the side stream buys nothing
     DeviceBuffer px, py, pz, cell_vert, cell_adj, alpha, q, bface;
+    double alpha_top = 0.0;      // largest alpha of the grid (c5_upload_grid / c5_update_scalars)
+    double edge_max = 0.0;       // longest edge of any cell: no view makes a cell longer along a ray
     double grid_diagonal = 0.0;  // of the grid's bounding box in object space: no rotation makes the grid longer along a ray
     double coord_max = 0.0;      // largest |coordinate| (what the rounding of an absolute depth scales with)
     FrameSlot slots[kFrameSlots];
@@ -587,6 +589,11 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     // walk_composite_lds addresses the records by 32-bit byte offsets: n_cells * 128 must fit
     wp.lds_stage = (ctx->lds_stage && ctx->n_cells < (int64_t{1} << 25)) ? ctx->lds_stage : 0;
     wp.counters = fs.counters.as<c5::FrameCounters>();
+    {   // every exp argument of this grid within (-1/8, 0]?  alpha_c <= min(limit, largest alpha), chord <= longest edge
+        double a_max = std::fmin(ctx->alpha_top, ctx->alpha_limit);
+        if (!(a_max >= 0.0)) a_max = ctx->alpha_top;  // (a NaN limit clamps nothing: line.cpp:216-218)
+        wp.small_exp_only = (a_max * ctx->edge_max < 0.125) ? 1 : 0;
+    }
     wp.row_cost = nullptr;
     wp.sb_cost = sb;
     wp.n_sb_rows = 0;
@@ -1031,6 +1038,20 @@ int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int3
         // within the largest |coordinate| + |x0|; the constant below has room for both)
         ctx->coord_max = top + 2.0;
     }
+    ctx->alpha_top = 0.0;
+    double edge2 = 0.0;
+    for (int64_t c = 0; c < n_cells; ++c) {
+        if (alpha[c] > ctx->alpha_top) ctx->alpha_top = alpha[c];  // (+inf counts: it is clamped to the limit; NaN never compares greater)
+        const int32_t* v = cell_vert + 4 * c;
+        for (int a = 0; a < 4; ++a)
+            for (int b = a + 1; b < 4; ++b) {
+                const double* pa = xyz + 3 * static_cast<int64_t>(v[a]);
+                const double* pb = xyz + 3 * static_cast<int64_t>(v[b]);
+                const double d2 = (pa[0] - pb[0]) * (pa[0] - pb[0]) + (pa[1] - pb[1]) * (pa[1] - pb[1]) + (pa[2] - pb[2]) * (pa[2] - pb[2]);
+                if (d2 > edge2) edge2 = d2;
+            }
+    }
+    ctx->edge_max = std::sqrt(edge2) * (1.0 + 1e-9);  // (the rotations round: a hair of margin)
     ctx->n_pts = n_pts;
     ctx->n_cells = n_cells;
     ctx->n_bfaces = static_cast<int64_t>(bfaces.size());
@@ -1050,6 +1071,9 @@ int c5_update_scalars(c5_context* ctx, const double* alpha, const double* q, int
         C5_HIP(ctx, hipMemcpy(ctx->q.ptr, q, static_cast<size_t>(n_cells) * 8, hipMemcpyHostToDevice));
     }
     for (FrameSlot& fs : ctx->slots) fs.optics_valid = fs.optics32_valid = false;
+    ctx->alpha_top = 0.0;
+    for (int64_t i = 0; i < n_cells; ++i)
+        if (alpha[i] > ctx->alpha_top) ctx->alpha_top = alpha[i];
     return C5_OK;
 }
 

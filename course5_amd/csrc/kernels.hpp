@@ -56,6 +56,10 @@ struct WalkParams {
     int32_t lds_pad;            // tuning: extra dynamic LDS per workgroup (bytes) to cap the resident wavefronts
     int32_t order;              // 0: back to front in the reference's arithmetic; 1: front to back + early-out
     FrameCounters* counters;
+    // 1: no step of this grid can give exp an argument beyond -1/8, whatever the view: min(alpha limit, largest alpha)
+    // times the longest edge of any cell stays below it (c_api.hip).  The walk then runs the instantiation that holds
+    // only the short exp series — neither the wave-wide test of the argument per step nor the general exp's code
+    int32_t small_exp_only;
     // rows of super-blocks (xcd_mode 2) start in the order of their cost in an earlier frame, dearest first (a launch
     // ends with its last wavefronts: let those be short ones): sb_order[k] = the k-th row to start, n_sb_rows of
     // them (0: image order); every wavefront adds its segments to sb_cost[its row] (nullptr: not collected).  The

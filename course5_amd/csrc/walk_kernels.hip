@@ -434,7 +434,8 @@ using LdsInts = const __attribute__((address_space(3))) int*;
 // SLOTS: distinct cells staged per wavefront and step: 14 (two DMA passes of seven), or 21 (three) for frames whose
 // pixels are coarse against the cells: more distinct cells per 8x8 tile — the host picks by the rays per cell of the
 // frame before (c_api.hip).
-template <int TILE, int ORDER, bool DMA = false, int SLOTS = kStageSlots>
+// SMALLEXP: every exp argument of the frame lies in (-1/8, 0] (WalkParams::small_exp_only): only the short series.
+template <int TILE, int ORDER, bool DMA = false, int SLOTS = kStageSlots, bool SMALLEXP = false>
 __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WALK_WAVES) void walk_composite_lds(WalkParams P) {
     constexpr int kStageSlots = SLOTS;  // (shadows the namespace constant: everything below is per instantiation)
     using TS = TileShape<TILE>;
@@ -773,7 +774,10 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
             // C3 walk 0.4786 -> 0.4738 ms, at 4800x3600 1.614 -> 1.579.  Starting the next step's election — ticket
             // written, winner read — before this arithmetic, so that the LDS round trip runs under it, cost a
             // register pair to scratch and 0.7 %: not kept)
-            const bool short_exp = !kEmitNow || __builtin_amdgcn_ballot_w64(contributes && !(pend_o0.y * dz < -kSmallExpArg)) == 0ull;
+            // With SMALLEXP (the host knows that no cell of the grid can give an argument beyond -1/8) neither the test nor
+            // the general exp is in the kernel: C3 walk 0.4735 -> 0.460 ms.  (The same knowledge as a per-frame flag
+            // read by the kernel, both paths kept, bought nothing: 0.4747 against 0.4741.)
+            const bool short_exp = SMALLEXP || !kEmitNow || __builtin_amdgcn_ballot_w64(contributes && !(pend_o0.y * dz < -kSmallExpArg)) == 0ull;
             if (contributes) {
                 ++n_seg;
                 tau = fma(dz, pend_o0.x, tau);  // line.cpp:189 (unclamped alpha); order-independent, done now
@@ -916,6 +920,19 @@ extern "C" int c5_debug_walk_stamps(unsigned long long* out16, int reset) {
 }
 #endif
 
+// the instantiation without the general exp (SMALLEXP), kept to the default tile shape: true if it took the launch
+template <int TILE, int ORDER>
+static bool launch_small_exp(hipStream_t s, const WalkParams& q, long long blocks, unsigned threads) {
+    if constexpr (TILE == 3) {
+        if (q.lds_stage == 2 && q.small_exp_only && q.stage_slots <= 16) {
+            hipLaunchKernelGGL((walk_composite_lds<3, ORDER, true, kStageSlots, true>), dim3(static_cast<unsigned>(blocks)), dim3(threads),
+                               static_cast<size_t>(q.lds_pad), s, q);
+            return true;
+        }
+    }
+    return false;
+}
+
 template <int TILE, int ORDER>
 static void launch_walk_t(hipStream_t s, const WalkParams& p) {
     using TS = TileShape<TILE>;
@@ -939,6 +956,8 @@ static void launch_walk_t(hipStream_t s, const WalkParams& p) {
         q.band_tiles = S;
         if (p.lds_stage == 2 && p.stage_slots > 16)
             hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true, 21>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, q);
+        else if (launch_small_exp<TILE, ORDER>(s, q, blocks, kThreads))
+            ;
         else if (p.lds_stage == 2)
             hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, q);
         else
@@ -958,6 +977,8 @@ static void launch_walk_t(hipStream_t s, const WalkParams& p) {
         q.band_tiles = band;
         if (p.lds_stage == 2 && p.stage_slots > 16)
             hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true, 21>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, q);
+        else if (launch_small_exp<TILE, ORDER>(s, q, blocks, kThreads))
+            ;
         else if (p.lds_stage == 2)
             hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, q);
         else if (p.lds_stage)

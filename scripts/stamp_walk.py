@@ -32,11 +32,11 @@ out = torch.zeros((1800, 2400, 2), dtype=torch.float32, device="cuda:0")
 buf = (C.c_ulonglong * 16)()
 names = ["election: ticket -> leader -> slot (2 LDS round trips)",
          "slot ids read back + staging loads (LDS-DMA) issued",
-         "emission / absorption of the previous step (exp), in the loads' shadow",
+         "(emission of the previous step in the loads' shadow: only in builds with C5_EMIT_NOW=0)",
          "staging loads land: s_waitcnt vmcnt(0)",
-         "10 x ds_read_b128 + four planes + exit face (+ re-entry)"]
-short = ["election", "issue", "emission", "load wait", "read + geometry"]
-lines = [f"# {tag}: phase clock of walk_composite_lds<3, 0, true, 16> on the C3 frame (2400x1800, fp64 walk)", "",
+         "8 x ds_read_b128 + three exit planes + exit face (+ re-entry) + this step's emission / absorption (exp)"]
+short = ["election", "issue", "deferred emission", "load wait", "read + geometry + emission"]
+lines = [f"# {tag}: phase clock of walk_composite_lds<3, 0, true, 14> (exit records, 8 wavefronts per SIMD) on the C3 frame (2400x1800, fp64 walk)", "",
          "`scripts/build_variant.sh stamps -DC5_WALK_STAMPS=1 && C5_LIB=course5_amd/libcourse5_hip_stamps.so python scripts/stamp_walk.py`",
          f"kernel sources: {kernel_source_hash()}", ""]
 result = {}

@@ -113,15 +113,18 @@ def write_roofline(tag, walk, c):
             # the launch spends its last quarter draining (one wavefront lives a third of the launch): while the slots
             # are full the units are busier than their average over the launch by the ratio of the step rates
             lim["steady_state_frac"] = min(1.0, busiest[1] * tl["steady_over_mean"])
+            per_step = (get("SQ_INSTS_VALU") or 0.0) / tl["wave_steps"] if tl.get("wave_steps") else None
+            lim["valu_per_wave_step"] = per_step
             lim["note"] = ("the busiest unit by its counter, averaged over the launch and (steady_state_frac) while the wavefront slots "
                            "are full (every vector instruction of a wave64 holds its SIMD for a quad-cycle, fp64 or not: "
-                           "SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU; ~84 per wavefront-step).  Two limits meet here: seven wavefronts "
-                           "x 84 quad-cycles fill 86 % of a SIMD's vector issue in the time ONE wavefront needs for a step, and that "
-                           "time is the step's dependent chain (phases: five LDS round trips, the staging loads, ~200 instructions in "
-                           "sequence) - a lone wavefront steps no faster (scripts/share_probe.py: 1.2 us per step at 30 % of the "
-                           "slots).  Hence: four vector instructions fewer per step change nothing (A/B 0.5419 vs 0.5406 ms), an eighth "
-                           "wavefront nothing, frames overlapped on a second stream +2.4 % (profiles/" + tag + "_overlap_probe.md); only "
-                           "shortening chain AND instruction count together pays (the mixed walk: half the LDS bytes, fp32 planes: -16 %)")
+                           "SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU; valu_per_wave_step of them per wavefront-step).  Two limits meet in "
+                           "this kernel: the vector issue of the resident wavefronts, and the time ONE wavefront needs for a step - its "
+                           "dependent chain (phases: LDS round trips, the staging loads, ~170 instructions in sequence); a lone "
+                           "wavefront steps no faster (profiles/" + tag + "_share_probe.md).  On the four-plane records of rounds 1-2 "
+                           "(84 vector instructions per step, seven wavefronts) fewer instructions alone, an eighth wavefront alone and "
+                           "frames overlapped on a second stream bought 0 / 0 / +2.4 %; the exit records (three planes, one line per "
+                           "cell) cut instructions, LDS bytes and registers together, and THEN the eighth wavefront paid: walk 0.540 -> "
+                           "0.474 ms (DESIGN.md section 4)")
         else:
             lim["note"] = "the busiest unit by its counter over the whole launch"
         out["limiter"] = lim
