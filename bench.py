@@ -18,7 +18,7 @@ roofline    of the dominant kernel walk_composite, every fraction <= 1 by constr
               limiter                  what actually binds the kernel: the busiest unit by the same PMC passes
                                        (VALU pipes, LDS, L2 requests, wavefront slots);
               contract                 SURVEY.md section 8(d)'s algorithmic figure (S * 144 B + P * 8 B) / duration —
-                                       NOT a fraction of anything: the 160 MB of per-view records are re-read
+                                       NOT a fraction of anything: the 128 MB of per-view records are re-read
                                        from L2 / Infinity Cache ~130 times per ray, so it exceeds the HBM peak.
 cpu_baseline  the CPU oracle (own restatement of the reference algorithm, OpenMP) timed on this box's
             host cores on the SAME workload at the SAME image size (rank 0, N = 1 only).  It is the checker
@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip
 HBM_ACHIEVABLE_GBS = 6290.0  # measured float4 copy, same table
 L2_PEAK_GBS = 34500.0        # aggregate L2, MI355X_MICROARCH.md "L2 (per XCD)"
 B_SEG_SURVEY = 144           # 16 cell->vertex + 16 adjacency + 96 vertices + 16 scalars
-B_SEG_RECORD = 160           # what walk_composite actually reads per step: 128 B CellRecord + 32 B CellOptics
+B_SEG_RECORD = 128           # what walk_composite actually reads per step: one 128 B ExitRecord (exit planes, neighbours, optics)
 B_PIX = 8                    # 2 x fp32 store per pixel
 TILE_ROWS = 16
 ROOFLINE_FILE = os.path.join(ROOT, "profiles", "roofline.json")  # written by scripts/summarize_profile.py
@@ -650,7 +650,7 @@ def main():
         roofline = {
             # `bound` names the unit the committed counters show busiest (profiles/<round>_pmc.md; `limiter` holds its
             # fraction over the whole launch and while the wavefront slots are full, `phases` where a wavefront-step
-            # spends its cycles, `timeline` how the launch fills and drains).  HBM is NOT it (14 %: the 160 MB of
+            # spends its cycles, `timeline` how the launch fills and drains).  HBM is NOT it (12 %: the 128 MB of
             # per-view records are served from L2 / Infinity Cache): achieved / peak / frac stay the HBM-side figures
             # the contract asks for — HBM bytes per launch over the live kernel time against 8 TB/s.
             "bound": bound_names.get(lim.get("name"), "hbm"),
@@ -668,7 +668,7 @@ def main():
             "source_hash": src_hash, "pmc_stale": pmc_stale,
             "contract": {
                 "what": "SURVEY.md section 8(d): algorithmic bytes (S x 144 B + P x 8 B) / kernel time. Not a fraction "
-                        "of a hardware limit: the per-view records (160 MB) are re-read from L2 / Infinity Cache, "
+                        "of a hardware limit: the per-view records (128 MB) are re-read from L2 / Infinity Cache, "
                         "HBM sees `traffic` bytes per launch",
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "achieved_gbs": round(alg_bytes / secs / 1e9, 1) if secs > 0 else None,

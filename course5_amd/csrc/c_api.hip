@@ -133,7 +133,7 @@ struct c5_context {
     uint32_t* host_sb = nullptr;  // pinned: the last frame's per-row costs
     int entry_key = 1;      // "entry_key": 1 = entries keyed a slack behind their face (hanging-node interfaces), 0 = at the face (testing)
     int optics_once = 1;    // "optics_once": the cells' optics are rebuilt only when scalars, limit or order changed
-    int stage_slots = 0;    // "stage_slots": 0 = chosen per frame from rays_per_cell, or 16 / 24
+    int stage_slots = 0;    // "stage_slots": 0 = chosen per frame from rays_per_cell, or 14 / 21
     double rays_per_cell = 0.0;  // of the last finished frame (0: none yet)
     int solid_cache = 1;    // a solid unchanged since the frame before is not rastered again (enqueue_solids)
     int overlap_setup = 0;  // measured: 1.27 vs 1.26 ms/frame, the side stream buys nothing
@@ -172,7 +172,7 @@ struct c5_context {
     int lds_pad = 0;
     int band_rows = 0;
     int order = 0;
-    double steep_ratio = 128.0;  // "precision" 1: cells whose fp32 plane terms exceed this many cell extents are evaluated in fp64
+    double steep_ratio = 64.0;   // "precision" 1: cells whose fp32 plane terms exceed this many cell extents are evaluated in fp64
     int precision = 0;  // 0: fp64 walk, bit-faithful (default); 1: fp32 geometry + fp64 accumulators (walk_mixed.hip)
     int lds_stage = 2;
     int stage_timing = 1;
@@ -583,7 +583,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     wp.max_steps = static_cast<uint32_t>(ctx->n_cells + 64);
     wp.xcd_mode = ctx->xcd_mode;
     wp.lds_pad = ctx->lds_pad;
-    wp.stage_slots = ctx->stage_slots ? ctx->stage_slots : (ctx->rays_per_cell > 0.0 && ctx->rays_per_cell < 120.0 ? 24 : 16);
+    wp.stage_slots = ctx->stage_slots ? ctx->stage_slots : (ctx->rays_per_cell > 0.0 && ctx->rays_per_cell < 120.0 ? 21 : 14);
     wp.band_rows = ctx->band_rows;
     wp.order = ctx->order;
     // walk_composite_lds addresses the records by 32-bit byte offsets: n_cells * 128 must fit
@@ -707,7 +707,7 @@ int finish_frame(c5_context* ctx) {
     }
     st.segments = static_cast<int64_t>(hc.segments);
     // How coarse the pixels are against the cells decides how many distinct cells an 8x8 tile meets per step, and
-    // with it how many staging slots the next frame's walk gets (walk_kernels.hip: 16 or 24): rays per cell of the
+    // with it how many staging slots the next frame's walk gets (walk_kernels.hip: 14 or 21): rays per cell of the
     // WHOLE frame, this context's share scaled up by the number of row shards.
     if (ctx->n_cells > 0 && hc.segments > 0)
         ctx->rays_per_cell = static_cast<double>(hc.segments) * static_cast<double>(ctx->im.world > 0 ? ctx->im.world : 1) *
@@ -1268,7 +1268,7 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
     } else if (n == "optics_once") {
         ctx->optics_once = static_cast<int>(value) != 0;
     } else if (n == "stage_slots") {
-        if (value != 0 && value != 16 && value != 24) return fail(ctx, C5_ERR_INVALID, "stage_slots must be 0 (per frame), 16 or 24");
+        if (value != 0 && value != 14 && value != 21) return fail(ctx, C5_ERR_INVALID, "stage_slots must be 0 (per frame), 14 or 21");
         ctx->stage_slots = static_cast<int>(value);
     } else if (n == "solid_cache") {
         ctx->solid_cache = static_cast<int>(value) != 0;

@@ -51,7 +51,7 @@ struct WalkParams {
     int32_t xcd_mode;
     int32_t band_tiles;         // xcd_mode 1: workgroup-tile rows per band (set by launch_walk)
     int32_t lds_stage;          // 2: walk_composite_lds with LDS-DMA staging, 1: staged through registers, 0: direct loads
-    int32_t stage_slots;        // lds_stage 1 / 2: <= 16 -> 14, more -> 21 distinct cells staged per wavefront and step (2 / 3 DMA passes of 7)
+    int32_t stage_slots;        // lds_stage 1 / 2: 14 or 21 distinct cells staged per wavefront and step (2 / 3 DMA passes of 7)
     int32_t band_rows;          // xcd_mode 1: image rows per band (0: 32)
     int32_t lds_pad;            // tuning: extra dynamic LDS per workgroup (bytes) to cap the resident wavefronts
     int32_t order;              // 0: back to front in the reference's arithmetic; 1: front to back + early-out

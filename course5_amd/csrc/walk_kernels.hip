@@ -924,7 +924,7 @@ extern "C" int c5_debug_walk_stamps(unsigned long long* out16, int reset) {
 template <int TILE, int ORDER>
 static bool launch_small_exp(hipStream_t s, const WalkParams& q, long long blocks, unsigned threads) {
     if constexpr (TILE == 3) {
-        if (q.lds_stage == 2 && q.small_exp_only && q.stage_slots <= 16) {
+        if (q.lds_stage == 2 && q.small_exp_only && q.stage_slots <= 14) {
             hipLaunchKernelGGL((walk_composite_lds<3, ORDER, true, kStageSlots, true>), dim3(static_cast<unsigned>(blocks)), dim3(threads),
                                static_cast<size_t>(q.lds_pad), s, q);
             return true;
@@ -954,7 +954,7 @@ static void launch_walk_t(hipStream_t s, const WalkParams& p) {
         blocks = 8ll * ((n_sb + 7) / 8) * S * S;
         WalkParams q = p;
         q.band_tiles = S;
-        if (p.lds_stage == 2 && p.stage_slots > 16)
+        if (p.lds_stage == 2 && p.stage_slots > 14)
             hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true, 21>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, q);
         else if (launch_small_exp<TILE, ORDER>(s, q, blocks, kThreads))
             ;
@@ -975,7 +975,7 @@ static void launch_walk_t(hipStream_t s, const WalkParams& p) {
         blocks = 8ll * rounds * band * tiles_x;
         WalkParams q = p;
         q.band_tiles = band;
-        if (p.lds_stage == 2 && p.stage_slots > 16)
+        if (p.lds_stage == 2 && p.stage_slots > 14)
             hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true, 21>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, q);
         else if (launch_small_exp<TILE, ORDER>(s, q, blocks, kThreads))
             ;
@@ -987,7 +987,7 @@ static void launch_walk_t(hipStream_t s, const WalkParams& p) {
             hipLaunchKernelGGL((walk_composite<TILE, ORDER>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, s, q);
         return;
     }
-    if (p.lds_stage == 2 && p.stage_slots > 16)
+    if (p.lds_stage == 2 && p.stage_slots > 14)
         hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true, 21>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, p);
     else if (p.lds_stage == 2)
         hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, p);

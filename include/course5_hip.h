@@ -156,7 +156,7 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  quarter faster; not bit-faithful, and a ray within ~1e-9 of a projected edge may count a
  *                  sliver more or less than the reference.
  *   "steep_ratio"  "precision" 1: a cell whose fp32 plane terms exceed this many times its extent along the rays is
- *                  evaluated from its fp64 record instead (default 128; 0: never).
+ *                  evaluated from its fp64 record instead (default 64; 0: never).
  *   "algorithm"    0 (default for conforming grids): face-adjacency walk.  1: bin_sort_resolve, the
  *                  reference's own algorithm on the GPU (every face of every cell scan-converted onto
  *                  the pixels, per-pixel sort by z, integrate) — handles tet soups, overlapping and
@@ -170,12 +170,14 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *   "cost_order"   1 (default): frames with fewer rays than about two rounds of the GPU's wavefront slots start the rows of
  *                  their image dearest first (by the cost per row of the last frame the caller waited for) instead
  *                  of top to bottom; 0: always top to bottom.  Same results.
- *   "optics_once"  1 (default): a cell's optics (alpha, clamped alpha, its reciprocal, Q: nothing of the view) are rebuilt
- *                  only after c5_upload_grid / c5_update_scalars or a change of the alpha limit or "integration", not
- *                  every frame; 0: every frame.  Same results.
- *   "stage_slots"  "lds_stage" 2: distinct cells staged per wavefront and step.  0 (default): 24 when the frame before had
- *                  fewer than 120 ray-cell segments per cell (pixels coarse against the cells: more distinct cells per
- *                  8x8 tile), else 16 (one more wavefront per SIMD); 16 / 24: fixed.  Same results either way.
+ *   "optics_once"  "precision" 1 only (the fp64 walk's 128-byte exit records carry the optics and are rebuilt whole every
+ *                  view).  1 (default): a cell's optics (alpha, clamped alpha, its reciprocal, Q: nothing of the view) are
+ *                  rebuilt only after c5_upload_grid / c5_update_scalars or a change of the alpha limit or "integration",
+ *                  not every frame; 0: every frame.  Same results.
+ *   "stage_slots"  "lds_stage" 1 / 2: distinct cells staged per wavefront and step (LDS-DMA passes of seven).  0 (default): 21
+ *                  when the frame before had fewer than 120 ray-cell segments per cell (pixels coarse against the cells:
+ *                  more distinct cells per 8x8 tile), else 14 (one more wavefront per SIMD); 14 / 21: fixed.  Same results
+ *                  either way.
  *   "tile"         wavefront tile: 0 = 64x1 row tile, 1 = 16x4, 2 = 8x8 pixels, four wavefronts per workgroup; 3 (default):
  *                  8x8 pixels, one wavefront per workgroup (its slot is free again when ITS rays are done).
  *   "xcd_mode"     how workgroups map to the 8 XCDs (blocks b and b + 8 share an L2): 2 (default): square

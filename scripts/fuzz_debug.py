@@ -15,6 +15,8 @@ o = Oracle("port")
 ref = o.render(xyz, cells, alpha, q, rots, res[0], res[1], mg.REFERENCE_BOUNDS, alpha_limit=limit, threads=8)
 ctx = capi.Context(0)
 ctx.upload_grid(xyz, cells, alpha, q); ctx.set_image(res[0], res[1], mg.REFERENCE_BOUNDS); ctx.set_view(rots); ctx.set_alpha_limit(limit)
+if os.environ.get("C5_STEEP_RATIO"):
+    ctx.set_option("steep_ratio", float(os.environ["C5_STEEP_RATIO"]))
 print("scene", seed, "cells", len(cells), "res", res, "S ref", ref["segments"], "covered", ref["covered"])
 for order in (0, 1):
     for key in (1, 0):

@@ -36,7 +36,7 @@ names = ["election: ticket -> leader -> slot (2 LDS round trips)",
          "staging loads land: s_waitcnt vmcnt(0)",
          "8 x ds_read_b128 + three exit planes + exit face (+ re-entry) + this step's emission / absorption (exp)"]
 short = ["election", "issue", "deferred emission", "load wait", "read + geometry + emission"]
-lines = [f"# {tag}: phase clock of walk_composite_lds<3, 0, true, 14> (exit records, 8 wavefronts per SIMD) on the C3 frame (2400x1800, fp64 walk)", "",
+lines = [f"# {tag}: phase clock of walk_composite_lds<3, 0, true, 14, true> (exit records, short exp series only, 8 wavefronts per SIMD) on the C3 frame (2400x1800, fp64 walk)", "",
          "`scripts/build_variant.sh stamps -DC5_WALK_STAMPS=1 && C5_LIB=course5_amd/libcourse5_hip_stamps.so python scripts/stamp_walk.py`",
          f"kernel sources: {kernel_source_hash()}", ""]
 result = {}

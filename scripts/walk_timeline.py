@@ -30,6 +30,7 @@ for k, v in opts.items():
     ctx.set_option(k, float(v))
 lib = capi.load_library()
 n_blocks = 131072
+SLOTS = 256 * 4 * int(os.environ.get("C5_WAVES", "8"))  # CUs x SIMDs x resident wavefronts per SIMD (launch bounds of the default kernel)
 buf = (C.c_ulonglong * (4 * n_blocks))()
 out = torch.zeros((res[1], res[0], 2), dtype=torch.float32, device="cuda:0")
 for _ in range(300):
@@ -54,12 +55,12 @@ lines = [f"# {tag}: launch timeline of the walk on the C3 frame ({res[0]}x{res[1
          f"steps per wavefront: median {np.median(steps):.0f}, max {steps.max()}; {np.median((e - b) * 1e3 / np.maximum(steps, 1)):.0f} ns per wavefront-step", ""]
 # slots in use over time
 grid = np.linspace(0, span, 41)
-lines += ["| time (us) | wavefronts with rays resident | of 7168 slots |", "|---|---|---|"]
+lines += [f"| time (us) | wavefronts with rays resident | of {SLOTS} slots |", "|---|---|---|"]
 for x in grid[:-1] + (grid[1] - grid[0]) / 2:
     n = int(((b <= x) & (e > x)).sum())
-    lines.append(f"| {x:.0f} | {n} | {n / 7168:.2f} |")
+    lines.append(f"| {x:.0f} | {n} | {n / SLOTS:.2f} |")
 busy = (e - b).sum()
-lines += ["", f"slot-time used by wavefronts with rays: {busy:.0f} us = {busy / (7168 * span):.3f} of 7168 slots x {span:.1f} us", ""]
+lines += ["", f"slot-time used by wavefronts with rays: {busy:.0f} us = {busy / (SLOTS * span):.3f} of {SLOTS} slots x {span:.1f} us", ""]
 lines += ["| XCD | wavefronts | wavefront-steps | first start (us) | last end (us) | slot-time (us) |", "|---|---|---|---|---|---|"]
 for x in sorted(set(xcc)):
     m = xcc == x
@@ -76,10 +77,10 @@ steady = rate[2:int(0.7 * 40)].mean()
 lines += ["", f"wavefront-steps per us: steady state (5 % - 70 % of the launch) {steady:.0f}, whole launch {steps.sum() / span:.0f} "
               f"(ratio {steady * span / steps.sum():.3f}); last fifth of the launch {rate[32:].mean():.0f}", ""]
 summary = {"round": tag, "source_hash": kernel_source_hash(), "span_us": round(float(span), 1), "wavefronts": int(len(t)),
-           "wave_steps": int(steps.sum()), "slot_time_frac": round(float(busy / (7168 * span)), 4),
+           "wave_steps": int(steps.sum()), "slot_time_frac": round(float(busy / (SLOTS * span)), 4),
            "steady_steps_per_us": round(float(steady), 1), "mean_steps_per_us": round(float(steps.sum() / span), 1),
            "steady_over_mean": round(float(steady * span / steps.sum()), 4),
-           "resident_frac_steady": round(float(np.mean([((b <= x) & (e > x)).sum() for x in edges[2:28]]) / 7168), 4),
+           "resident_frac_steady": round(float(np.mean([((b <= x) & (e > x)).sum() for x in edges[2:28]]) / SLOTS), 4),
            "tail_starts_us": round(float(order[int(len(order) * 0.5)]), 1) if False else None,
            "median_wave_life_us": round(float(np.median(e - b)), 1), "source": f"profiles/{tag}_walk_timeline.md"}
 # tail: when does the number of resident wavefronts fall below half the slots for good

@@ -17,7 +17,7 @@ from course5_amd import capi, meshgen as mg
 from oracle.pyoracle import Oracle
 
 # (lds_stage, integration, tile); the first one is the product default
-# lds_stage 3 here: LDS-DMA staging with 24 slots ("stage_slots" 24)
+# lds_stage 3 here: LDS-DMA staging with 21 slots ("stage_slots" 21)
 VARIANTS = ((2, 0, 3), (1, 0, 0), (2, 1, 3), (0, 0, 1), (2, 0, 1), (0, 1, 0), (1, 1, 1), (3, 0, 3), (1, 0, 2), (3, 1, 1), (2, 0, 0), (2, 0, 2), (1, 1, 3), (0, 0, 3))
 
 
@@ -72,7 +72,7 @@ def main():
         ctx.set_view(rots)
         ctx.set_alpha_limit(limit)
         for lds, order, tile in VARIANTS:
-            ctx.set_option("lds_stage", min(lds, 2)); ctx.set_option("stage_slots", 24 if lds == 3 else 16)
+            ctx.set_option("lds_stage", min(lds, 2)); ctx.set_option("stage_slots", 21 if lds == 3 else 14)
             ctx.set_option("integration", order); ctx.set_option("tile", tile)
             img = ctx.render(); st = ctx.stats()
             a, b = img.astype(np.float64), ref["image"].astype(np.float64)

@@ -40,7 +40,7 @@ def test_random_scenes_match_the_oracle(gpu_ctx, oracle_port, block):
         gpu_ctx.set_alpha_limit(limit)
         lds, order, tile = fuzz.VARIANTS[k % len(fuzz.VARIANTS)]
         gpu_ctx.set_option("lds_stage", min(lds, 2))
-        gpu_ctx.set_option("stage_slots", 24 if lds == 3 else 16)
+        gpu_ctx.set_option("stage_slots", 21 if lds == 3 else 14)
         gpu_ctx.set_option("integration", order)
         gpu_ctx.set_option("tile", tile)
         img = gpu_ctx.render()
