@@ -47,5 +47,6 @@ with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
     base = min(ms for n, ms, _ in rows if n == 1)
     f.write(f"\nBest of N = 2: {100 * (base / min(ms for n, ms, _ in rows if n == 2) - 1):.1f} %, of N = 3: "
             f"{100 * (base / min(ms for n, ms, _ in rows if n == 3) - 1):.1f} % over one context.  Setup of frame k + 1 on a low-priority stream "
-            "beside walk k inside ONE context (option \"pipeline\" 1) LOSES: 0.756 against 0.621 ms per frame, the walk itself 0.608 against "
-            "0.537 ms (two sets of 160 MB records in flight against a 256 MB Infinity Cache).\n")
+            "beside walk k inside ONE context (option \"pipeline\" 1) loses a little: 0.5525 against 0.5460 ms per frame, the walk itself 0.522 against "
+            "0.459 ms; whole frames alternating between two streams of one context: 0.5428 ms (scripts/opt_probe.py, round 3).  What a frame's drain leaves "
+            "idle is not free capacity: the next frame's setup and first wavefronts lengthen the memory latency the last wavefronts' steps wait on.\n")

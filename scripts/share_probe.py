@@ -26,7 +26,7 @@ def timed():
 
 lines = ["# r03: which walk kernel on a SMALL share of the frame (what one of 8 GPUs renders)?  `python scripts/share_probe.py`", "",
          "walk = best of 8 after 30 warm frames, HIP events; a share that fills a third of the wavefront slots lasts as long as one wavefront's life: "
-         "steps x per-step latency, and a lone wavefront's step is no shorter than one among seven (1.2 us)", "",
+         "steps x per-step latency, and a lone wavefront's step is no shorter than one among eight (1.1 us)", "",
          "| image | rows (first, count) | lds_stage | tile | precision | walk ms | frame ms | covered pixels |", "|---|---|---|---|---|---|---|---|"]
 for res, rows in (((2400, 1800), (838, 124)), ((2400, 1800), (0, 514)), ((2400, 1800), (776, 248)), ((4800, 3600), (1676, 248))):
     ctx.set_row_range(0, -1)
