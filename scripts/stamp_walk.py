@@ -25,10 +25,13 @@ xyz, c, a, q = mg.workload("c3")
 ctx.upload_grid(xyz, c, a, q)
 ctx.set_image(2400, 1800, mg.REFERENCE_BOUNDS)
 ctx.set_view(mg.view_rotations(0.1, 0.07))
+rows = os.environ.get("C5_ROWS")  # "first,count": the phase clock of a small share of the frame (few wavefronts per SIMD); nothing written
+if rows:
+    ctx.set_row_range(*(int(v) for v in rows.split(",")))
 lib = capi.load_library()
 if not hasattr(lib, "c5_debug_walk_stamps"):
     raise SystemExit("this library was not built with -DC5_WALK_STAMPS=1 (scripts/build_variant.sh stamps -DC5_WALK_STAMPS=1)")
-out = torch.zeros((1800, 2400, 2), dtype=torch.float32, device="cuda:0")
+out = torch.zeros((ctx.local_rows if rows else 1800, 2400, 2), dtype=torch.float32, device="cuda:0")
 buf = (C.c_ulonglong * 16)()
 names = ["election: ticket -> leader -> slot (2 LDS round trips)",
          "slot ids read back + staging loads (LDS-DMA) issued",
@@ -68,6 +71,8 @@ for stage, label in ((2, "LDS-DMA staging (default)"), (1, "staged through vecto
                   "walking_lanes_per_step": round(v[13] / steps, 2), "source": f"profiles/{tag}_walk_phases.md"}
 text = "\n".join(lines) + "\n"
 print(text)
+if rows:
+    raise SystemExit(0)
 with open(os.path.join(ROOT, "profiles", f"{tag}_walk_phases.md"), "w") as f:
     f.write(text)
 with open(os.path.join(ROOT, "profiles", f"{tag}_walk_phases.json"), "w") as f:
