@@ -578,6 +578,10 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
     const unsigned long long trace_begin_ = __builtin_amdgcn_s_memrealtime();
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned stat_runs = 0, stat_distinct = 0, stat_iters = 0, stat_lanes = 0;
+#if C5_WALK_STAMPS > 1
+    unsigned stat_next_staged = 0, stat_next_total = 0;
+    int nb_before_ = -1;
+#endif
     unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
     const unsigned long long t_begin_ = t_prev_;
 #endif
@@ -809,8 +813,22 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
                 nxt = next_entry<kUp>(P, lp, load_entry_head(P.entry_head + lp), w_cur, carry);
                 my_scur[lane] = w_cur;
             }
+#if C5_WALK_STAMPS > 1
+            nb_before_ = nb;
+#endif
             nb = nxt;
         }
+#if C5_WALK_STAMPS > 1
+        if (stamping_) {  // how often is a ray's NEXT cell one this step already staged (some lane's current cell)?
+            bool hit = false;
+            for (int l = 0; l < 64; ++l) {
+                const int v = __builtin_amdgcn_readlane(nb_before_, l);
+                if (v >= 0 && need && nb == v) hit = true;
+            }
+            stat_next_staged += static_cast<unsigned>(__popcll(__builtin_amdgcn_ballot_w64(hit)));
+            stat_next_total += static_cast<unsigned>(__popcll(__builtin_amdgcn_ballot_w64(need && nb >= 0)));
+        }
+#endif
 #if C5_WALK_STAMPS
         if (stamping_) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         C5_STAMP(4);  // record read back, geometry, exit face, (re-entry)
@@ -833,6 +851,10 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
         atomicAdd(&g_walk_stamps[9], 1ull);                                      // wavefronts
         atomicAdd(&g_walk_stamps[10], static_cast<unsigned long long>(stat_runs));
         atomicAdd(&g_walk_stamps[11], static_cast<unsigned long long>(stat_distinct));
+#if C5_WALK_STAMPS > 1
+        atomicAdd(&g_walk_stamps[14], static_cast<unsigned long long>(stat_next_staged));
+        atomicAdd(&g_walk_stamps[15], static_cast<unsigned long long>(stat_next_total));
+#endif
         atomicAdd(&g_walk_stamps[12], static_cast<unsigned long long>(stat_iters));
         atomicAdd(&g_walk_stamps[13], static_cast<unsigned long long>(stat_lanes));
     }

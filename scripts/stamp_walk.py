@@ -63,6 +63,9 @@ for stage, label in ((2, "LDS-DMA staging (default)"), (1, "staged through vecto
               "| phase | cycles | share | cycles per wavefront-step |", "|---|---|---|---|"]
     for n, x in zip(names, v[:5]):
         lines.append(f"| {n} | {x} | {100.0 * x / tot:.1f} % | {x / steps:.2f} |")
+    if v[15]:
+        lines.append(f"\n(-DC5_WALK_STAMPS=2) distinct cells per wavefront-step {v[11] / steps:.2f} (runs of equal ids {v[10] / steps:.2f}); "
+                     f"a ray's NEXT cell is one this step already staged for some lane: {100.0 * v[14] / v[15]:.1f} % of {v[15]} lane-steps")
     lines.append("")
     if stage == 2:
         k = max(range(5), key=lambda i: v[i])
