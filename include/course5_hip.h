@@ -152,9 +152,12 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *   "precision"    0 (default): the fp64 walk — images equal the reference's to the last bit of their fp32
  *                  values, segment counts equal plane::count_all_intersections.  1: fp32 face planes about a
  *                  cell-local origin on the pixel lattice (64-byte records), fp32 series for exp(-alpha dz) - 1,
- *                  fp64 only for the tau and I accumulators: within the 1e-5 bar (about 1e-6 in practice), a
- *                  quarter faster; not bit-faithful, and a ray within ~1e-9 of a projected edge may count a
- *                  sliver more or less than the reference.
+ *                  fp64 only for the tau and I accumulators: within the 1e-5 bar on every fixture (about 1e-6 in
+ *                  practice); not bit-faithful, and NOT robust where fp32 cannot tell two exit faces apart: a ray
+ *                  within ~1e-8 of a projected edge may count a sliver more or less than the reference, and if that
+ *                  edge lies on the grid's boundary it can take the wrong face out of the grid and lose the rest of
+ *                  the ray (randomised sweep, round 3: 1 ray in 1.4e7; single pixels at 1e-4 in 3 scenes of 3 000).
+ *                  No faster than the fp64 walk since round 3: use the default.
  *   "steep_ratio"  "precision" 1: a cell whose fp32 plane terms exceed this many times its extent along the rays is
  *                  evaluated from its fp64 record instead (default 64; 0: never).
  *   "algorithm"    0 (default for conforming grids): face-adjacency walk.  1: bin_sort_resolve, the
