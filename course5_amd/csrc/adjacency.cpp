@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 
 namespace c5 {
@@ -299,11 +300,50 @@ void unique_solid_faces(const double* tets, int64_t n_tets, std::vector<double>&
     // of init_polar are angular neighbours, so consecutive faces cover neighbouring pixels of the same
     // image rows (coalesced mask accesses); faces through vertex 0 (the fan centre: long slivers) go
     // first and the short surface faces (slot 3) last, so a wavefront holds faces of similar height.
+    //
+    // INTERIOR faces.  A face that has a cell of non-zero volume on EITHER side covers no pixel its solid's other faces
+    // do not cover: a ray through it runs on through both cells and leaves each through another face, and so on until
+    // it meets a face with nothing behind it (finitely many cells, the depth grows with every cell) - the mask is the
+    // union over all faces (plane.cpp:130-131 -> line.cpp:246-249), so such a face is pure overdraw: on the centre-fan
+    // solids of the reference the three fan faces of every cell (long slivers from the centre to the surface: 460 times
+    // the pixels of the surface triangles together).  Marked in the face's fourth word and sorted to the front, so that
+    // the raster can start behind them (c_api.hip, option "solid_interior_faces").  Sides by the sign of the cell's fourth
+    // vertex against the face through its three (sorted, hence shared) point ids; a cell too flat to have a side
+    // (|det| <= 1e-9 of the product of its edge lengths: the duplicated points at the poles of init_polar) counts for
+    // neither, and a face with cells on one side only is a boundary face whatever its multiplicity.
+    auto side_of = [&](const FaceKey& k) {
+        const uint32_t t = k.ref >> 2, f = k.ref & 3u;
+        const double* pa = &points[3 * static_cast<size_t>(k.a)];
+        const double* pb = &points[3 * static_cast<size_t>(k.b)];
+        const double* pc = &points[3 * static_cast<size_t>(k.c)];
+        const double* pd = &tets[3 * (4 * static_cast<size_t>(t) + (3u - f))];  // FV[f] leaves out vertex 3 - f
+        const double u[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+        const double v[3] = {pc[0] - pa[0], pc[1] - pa[1], pc[2] - pa[2]};
+        const double w[3] = {pd[0] - pa[0], pd[1] - pa[1], pd[2] - pa[2]};
+        const double det = u[0] * (v[1] * w[2] - v[2] * w[1]) - u[1] * (v[0] * w[2] - v[2] * w[0]) + u[2] * (v[0] * w[1] - v[1] * w[0]);
+        auto len = [](const double* q) { return std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]); };
+        const double scale = len(u) * len(v) * len(w);
+        if (!(std::fabs(det) > 1e-9 * scale)) return 0;
+        return det > 0.0 ? 1 : -1;
+    };
     std::vector<FaceKey> uniq;
+    std::vector<uint8_t> interior_of_ref(static_cast<size_t>(n_raw), 0);
     uniq.reserve(keys.size());
-    for (size_t i = 0; i < keys.size(); ++i)
-        if (i == 0 || !key_eq(keys[i - 1], keys[i])) uniq.push_back(keys[i]);
-    parallel_sort(uniq, [](const FaceKey& l, const FaceKey& r) {
+    for (size_t i = 0; i < keys.size();) {
+        size_t j = i;
+        bool above = false, below = false;
+        for (; j < keys.size() && key_eq(keys[i], keys[j]); ++j) {
+            const int sd = side_of(keys[j]);
+            above = above || sd > 0;
+            below = below || sd < 0;
+        }
+        uniq.push_back(keys[i]);
+        interior_of_ref[keys[i].ref] = (above && below) ? 1 : 0;
+        i = j;
+    }
+    parallel_sort(uniq, [&](const FaceKey& l, const FaceKey& r) {
+        const bool li = interior_of_ref[l.ref] != 0, ri = interior_of_ref[r.ref] != 0;
+        if (li != ri) return li;  // interior faces first
         const bool ls = (l.ref & 3u) == 3u, rs = (r.ref & 3u) == 3u;
         if (ls != rs) return !ls;
         return l.ref < r.ref;
@@ -314,7 +354,7 @@ void unique_solid_faces(const double* tets, int64_t n_tets, std::vector<double>&
         faces.push_back(static_cast<int32_t>(k.a));
         faces.push_back(static_cast<int32_t>(k.b));
         faces.push_back(static_cast<int32_t>(k.c));
-        faces.push_back(0);
+        faces.push_back(interior_of_ref[k.ref]);
     }
 }
 

@@ -27,9 +27,10 @@ int64_t weld_points(const double* xyz, int64_t n_pts, std::vector<int32_t>& rep)
 // Solid tet soup [n][4][3] -> unique points (bitwise equal coordinates merged) and unique faces
 // (unordered point-id triples; 4 per tet before merging).  The centre-fan solids of the reference
 // (object3d_base.cpp:152-193) share every sliver face between two cells and every point between ~24,
-// and the mask raster only depends on a face's three points, so duplicates are pure overdraw.
+// and the mask raster only depends on a face's three points, so duplicates are pure overdraw.  Faces with a cell of
+// non-zero volume on either side (interior: they cover nothing the others do not) come first, marked 1.
 void unique_solid_faces(const double* tets, int64_t n_tets, std::vector<double>& points,
-                        std::vector<int32_t>& faces /* 4 ints per face: a, b, c, 0 */);
+                        std::vector<int32_t>& faces /* 4 ints per face: a, b, c, interior ? 1 : 0 */);
 
 // memcpy on the host threads this process may use (a single thread moves ~10 GB/s: 3.5 ms for a 2400x1800
 // image, five times the PCIe transfer it follows).

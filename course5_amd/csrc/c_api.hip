@@ -54,8 +54,19 @@ struct Solid {
     int64_t n_tets = 0;      // as given
     int64_t n_points = 0;    // unique points
     int64_t n_faces = 0;     // unique faces
+    int64_t n_interior = 0;  // of them, at the head of the list: faces with a cell on either side (adjacency.hpp)
     double colour = 0.0;
-    double typical_edge = 0.0;  // mean over the unique faces of their longest edge (object units)
+    // The faces in groups of about the same size (binary exponent of the longest edge, longest first; the interior faces'
+    // groups before the others'): solid_mask_raster gives a face as many lanes as its rows ask for, and what a launch
+    // lasts is the longest chain of rows ONE lane walks - the 130 000 surface triangles of the Roche lobe are a few pixels
+    // each, its few hundred closing faces (object3d_base.cpp:171-174) span the whole solid.
+    struct FaceGroup {
+        int64_t begin, count;
+        double longest;  // edge, object units (no rotation makes a face taller)
+    };
+    std::vector<FaceGroup> groups;
+    double centre[3] = {0, 0, 0};        // bounding sphere of the points (object space)
+    double radius = 0.0;
     DeviceBuffer raw;        // unique points [m][3]
     DeviceBuffer faces;      // unique faces, int4 (a, b, c, 0)
     DeviceBuffer view[2];    // transformed points, one per frame slot
@@ -136,6 +147,7 @@ struct c5_context {
     int stage_slots = 0;    // "stage_slots": 0 = chosen per frame from rays_per_cell, or 14 / 21
     double rays_per_cell = 0.0;  // of the last finished frame (0: none yet)
     int solid_cache = 1;    // a solid unchanged since the frame before is not rastered again (enqueue_solids)
+    int solid_interior_faces = 0;  // 1: interior faces are rastered too (they cover nothing the others do not; testing)
     int overlap_setup = 0;  // measured: 1.27 vs 1.26 ms/frame, the side stream buys nothing
     DeviceBuffer px, py, pz, cell_vert, cell_adj, alpha, q, bface;
     double alpha_top = 0.0;      // largest alpha of the grid (c5_upload_grid / c5_update_scalars)
@@ -337,12 +349,61 @@ int enqueue_solids(c5_context* ctx, FrameSlot& fs, int slot_id, hipStream_t s, c
                 target = so.own_mask.as<uint32_t>();
             }
             c5::launch_transform_aos(s, so.raw.as<double>(), so.view[slot_id].as<double>(), so.n_points, so.rots);
-            // lanes per face: about one per eight image rows of a typical face, a power of two up to 16
-            const double rows = so.typical_edge / std::fabs(im.step_y);
-            int lanes = 1;
-            while (lanes < 16 && rows > 8.0 * lanes) lanes *= 2;
-            c5::launch_solid_mask_raster(s, so.view[slot_id].as<double>(), so.faces.as<int4>(), so.n_faces,
-                                         static_cast<uint32_t>(k) + 1u, ctx->ytab.as<double>(), im, target, lanes);
+            // Interior faces (a cell on either side: they cover no pixel the solid's other faces do not) are skipped -
+            // where get_pixel_by_x/_y's clamp has no hand in their pixels (plane.cpp:194-212: what a face beyond a
+            // border smears onto it is NOT the projection of anything).  A solid whose bounding sphere lies inside
+            // the domain: none of them is even launched; one that reaches a border: each interior face decides for
+            // itself (solid_mask_raster, only_across_border).
+            int64_t skip = 0;
+            const bool filter_interior = !ctx->solid_interior_faces && so.n_interior > 0 && so.n_interior < so.n_faces;
+            if (filter_interior) {
+                double c[3] = {so.centre[0], so.centre[1], so.centre[2]};
+                for (int r = 0; r < so.rots.n; ++r) {  // tetra.cpp:44-62, as rotate_point on the device
+                    const double co = so.rots.cosv[r], si = so.rots.sinv[r];
+                    if (so.rots.axis[r] == 0) {
+                        const double y_old = c[1];
+                        c[1] = c[1] * co - c[2] * si;
+                        c[2] = y_old * si + c[2] * co;
+                    } else {
+                        c[0] -= so.rots.x0[r];
+                        const double x_old = c[0];
+                        c[0] = c[0] * co - c[2] * si;
+                        c[2] = x_old * si + c[2] * co;
+                        c[0] += so.rots.x0[r];
+                    }
+                }
+                const double pad = so.radius * (1.0 + 1e-9) + 2.0 * std::fmax(std::fabs(im.step_x), std::fabs(im.step_y));
+                const double x_a = im.x_min, x_b = im.x_min + im.step_x * (im.res_x - 1);
+                const double y_a = im.y_min, y_b = im.y_min + im.step_y * (im.res_y - 1);
+                if (c[0] - pad > std::fmin(x_a, x_b) && c[0] + pad < std::fmax(x_a, x_b) && c[1] - pad > std::fmin(y_a, y_b) &&
+                    c[1] + pad < std::fmax(y_a, y_b))
+                    skip = so.n_interior;
+            }
+            // lanes per face: about one per eight image rows of the group's tallest face, a power of two up to 64;
+            // neighbouring groups that come to the same number share a launch
+            int64_t run_begin = -1, run_count = 0;
+            int run_lanes = 0;
+            bool run_filtered = false;
+            auto flush = [&]() {
+                if (run_count > 0)
+                    c5::launch_solid_mask_raster(s, so.view[slot_id].as<double>(), so.faces.as<int4>() + run_begin, run_count,
+                                                 static_cast<uint32_t>(k) + 1u, ctx->ytab.as<double>(), im, target, run_lanes,
+                                                 run_filtered);
+                run_count = 0;
+            };
+            for (const Solid::FaceGroup& g : so.groups) {
+                if (g.begin < skip) continue;  // an interior group of a solid inside the domain
+                const bool filtered = filter_interior && g.begin < so.n_interior;
+                // a lane per eight rows of the group's tallest face while the group alone does not fill the GPU, per
+                // thirty-two once it does (every lane of a face repeats the face's set-up)
+                const double rows = g.longest / std::fabs(im.step_y);
+                int lanes = 1;
+                while (lanes < 64 && rows > 8.0 * lanes && (g.count * lanes < (int64_t{1} << 18) || rows > 32.0 * lanes)) lanes *= 2;
+                if (run_count > 0 && (lanes != run_lanes || filtered != run_filtered || g.begin != run_begin + run_count)) flush();
+                if (run_count == 0) run_begin = g.begin, run_lanes = lanes, run_filtered = filtered;
+                run_count += g.count;
+            }
+            flush();
             if (target != fs.mask.as<uint32_t>()) {
                 so.own_mask_ready = true;
                 c5::launch_mask_overlay(s, so.own_mask.as<uint32_t>(), fs.mask.as<uint32_t>(), padded);
@@ -1093,6 +1154,8 @@ int c5_set_solid(c5_context* ctx, int slot, const double* tets, int64_t n_tets, 
     s.n_tets = n_tets;
     s.colour = colour;
     s.n_points = s.n_faces = 0;
+    s.n_interior = 0;
+    s.groups.clear();
     ++s.generation;  // whatever mask of its own the slot had is stale
     s.own_mask_ready = false;
     if (n_tets > 0) {
@@ -1101,18 +1164,58 @@ int c5_set_solid(c5_context* ctx, int slot, const double* tets, int64_t n_tets, 
         c5::unique_solid_faces(tets, n_tets, pts, faces);
         s.n_points = static_cast<int64_t>(pts.size() / 3);
         s.n_faces = static_cast<int64_t>(faces.size() / 4);
-        {   // how tall a face typically is decides how many lanes share one face in solid_mask_raster
-            double sum = 0.0;
-            for (size_t f = 0; f < faces.size() / 4; ++f) {
+        s.n_interior = 0;
+        while (s.n_interior < s.n_faces && faces[4 * static_cast<size_t>(s.n_interior) + 3] != 0) ++s.n_interior;
+        {   // bounding sphere about the centre of the bounding box (no rotation makes the solid reach further)
+            double lo[3] = {pts[0], pts[1], pts[2]}, hi[3] = {pts[0], pts[1], pts[2]};
+            for (size_t i = 0; i < pts.size(); i += 3)
+                for (int d = 0; d < 3; ++d) lo[d] = std::min(lo[d], pts[i + d]), hi[d] = std::max(hi[d], pts[i + d]);
+            for (int d = 0; d < 3; ++d) s.centre[d] = 0.5 * (lo[d] + hi[d]);
+            double r2 = 0.0;
+            for (size_t i = 0; i < pts.size(); i += 3) {
+                double q = 0.0;
+                for (int d = 0; d < 3; ++d) q += (pts[i + d] - s.centre[d]) * (pts[i + d] - s.centre[d]);
+                r2 = std::max(r2, q);
+            }
+            s.radius = std::sqrt(r2);
+        }
+        {   // groups of faces of about the same size (see Solid::FaceGroup), the generator's order kept inside a group:
+            // consecutive cells of init_polar are angular neighbours, their faces cover neighbouring pixels
+            const size_t nf = faces.size() / 4;
+            std::vector<double> edge(nf);
+            std::vector<int> cls(nf);
+            for (size_t f = 0; f < nf; ++f) {
                 const double* a = &pts[3 * static_cast<size_t>(faces[4 * f])];
                 const double* b = &pts[3 * static_cast<size_t>(faces[4 * f + 1])];
                 const double* c = &pts[3 * static_cast<size_t>(faces[4 * f + 2])];
                 auto d2 = [](const double* u, const double* v) {
                     return (u[0] - v[0]) * (u[0] - v[0]) + (u[1] - v[1]) * (u[1] - v[1]) + (u[2] - v[2]) * (u[2] - v[2]);
                 };
-                sum += std::sqrt(std::max(d2(a, b), std::max(d2(b, c), d2(a, c))));
+                edge[f] = std::sqrt(std::max(d2(a, b), std::max(d2(b, c), d2(a, c))));
+                int e = -1000;
+                if (edge[f] > 0.0 && std::isfinite(edge[f])) (void)std::frexp(edge[f], &e);
+                cls[f] = e;
             }
-            s.typical_edge = s.n_faces ? sum / static_cast<double>(s.n_faces) : 0.0;
+            std::vector<uint32_t> order(nf);
+            for (size_t f = 0; f < nf; ++f) order[f] = static_cast<uint32_t>(f);
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t l, uint32_t r) {
+                const bool li = static_cast<int64_t>(l) < s.n_interior, ri = static_cast<int64_t>(r) < s.n_interior;
+                if (li != ri) return li;
+                return cls[l] > cls[r];
+            });
+            std::vector<int32_t> sorted(faces.size());
+            s.groups.clear();
+            for (size_t k = 0; k < nf; ++k) {
+                const uint32_t f = order[k];
+                for (int d = 0; d < 4; ++d) sorted[4 * k + d] = faces[4 * static_cast<size_t>(f) + d];
+                const bool interior = static_cast<int64_t>(f) < s.n_interior;
+                const bool was_interior = k > 0 && static_cast<int64_t>(order[k - 1]) < s.n_interior;
+                if (k == 0 || cls[f] != cls[order[k - 1]] || interior != was_interior)
+                    s.groups.push_back(Solid::FaceGroup{static_cast<int64_t>(k), 0, 0.0});
+                s.groups.back().count += 1;
+                s.groups.back().longest = std::max(s.groups.back().longest, edge[f]);
+            }
+            faces.swap(sorted);
         }
         const size_t bytes = pts.size() * sizeof(double);
         C5_HIP(ctx, s.raw.ensure(bytes));
@@ -1270,6 +1373,9 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
     } else if (n == "stage_slots") {
         if (value != 0 && value != 14 && value != 21) return fail(ctx, C5_ERR_INVALID, "stage_slots must be 0 (per frame), 14 or 21");
         ctx->stage_slots = static_cast<int>(value);
+    } else if (n == "solid_interior_faces") {
+        ctx->solid_interior_faces = static_cast<int>(value) != 0;
+        for (Solid& so : ctx->solids) so.own_mask_ready = false, so.unchanged_frames = 0, so.seen_generation = ~uint64_t{0};
     } else if (n == "solid_cache") {
         ctx->solid_cache = static_cast<int>(value) != 0;
         for (Solid& so : ctx->solids) so.own_mask_ready = false, so.unchanged_frames = 0, so.seen_generation = ~uint64_t{0};

@@ -197,16 +197,29 @@ struct FaceScan {
 __global__ __launch_bounds__(256) void solid_mask_raster(const double* __restrict__ pts,
                                                          const int4* __restrict__ faces, int64_t n_faces,
                                                          uint32_t value, const double* __restrict__ Ytab,
-                                                         ImageParams im, uint32_t* __restrict__ mask, int lanes_log2) {
+                                                         ImageParams im, uint32_t* __restrict__ mask, int lanes_log2,
+                                                         int only_across_border) {
     const int64_t tid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
     const int64_t gid = tid >> lanes_log2;
     const long long sub = static_cast<long long>(tid & ((1ll << lanes_log2) - 1)), n_sub = 1ll << lanes_log2;
     if (gid >= n_faces) return;
     const int4 fc = faces[gid];
+    const double ax = pts[3 * static_cast<size_t>(fc.x)], ay = pts[3 * static_cast<size_t>(fc.x) + 1];
+    const double bx = pts[3 * static_cast<size_t>(fc.y)], by = pts[3 * static_cast<size_t>(fc.y) + 1];
+    const double cx = pts[3 * static_cast<size_t>(fc.z)], cy = pts[3 * static_cast<size_t>(fc.z) + 1];
+    if (only_across_border) {
+        // an INTERIOR face of its solid (c_api.hip: enqueue_solids): it covers nothing the solid's other faces do not
+        // cover - unless get_pixel_by_x/_y's clamp (plane.cpp:194-212) has a hand in its pixels; a face that lies a
+        // pixel inside the domain on every side is left out
+        const double x_a = im.x_min, x_b = im.x_min + im.step_x * (im.res_x - 1);
+        const double y_a = im.y_min, y_b = im.y_min + im.step_y * (im.res_y - 1);
+        const double mx = 2.0 * fabs(im.step_x), my = 2.0 * fabs(im.step_y);
+        if (fmin(ax, fmin(bx, cx)) > fmin(x_a, x_b) + mx && fmax(ax, fmax(bx, cx)) < fmax(x_a, x_b) - mx &&
+            fmin(ay, fmin(by, cy)) > fmin(y_a, y_b) + my && fmax(ay, fmax(by, cy)) < fmax(y_a, y_b) - my)
+            return;
+    }
     FaceScan fs;
-    fs.setup(pts[3 * static_cast<size_t>(fc.x)], pts[3 * static_cast<size_t>(fc.x) + 1],
-             pts[3 * static_cast<size_t>(fc.y)], pts[3 * static_cast<size_t>(fc.y) + 1],
-             pts[3 * static_cast<size_t>(fc.z)], pts[3 * static_cast<size_t>(fc.z) + 1], im);
+    fs.setup(ax, ay, bx, by, cx, cy, im);
     for (long long row = fs.row_lo + sub; row <= fs.row_hi; row += n_sub) {
         const int lrow = local_row_of(im, static_cast<int>(row));
         if (lrow < 0) continue;
@@ -536,14 +549,14 @@ void launch_mask_overlay(hipStream_t s, const uint32_t* src, uint32_t* dst, int6
 
 void launch_solid_mask_raster(hipStream_t s, const double* pts, const int4* faces, int64_t n_faces,
                               uint32_t value, const double* Ytab, const ImageParams& im, uint32_t* mask,
-                              int lanes_per_face) {
+                              int lanes_per_face, bool only_across_border) {
     if (n_faces <= 0) return;
     int lanes_log2 = 0;
     while ((2 << lanes_log2) <= lanes_per_face && lanes_log2 < 6) ++lanes_log2;
     const int64_t threads = n_faces << lanes_log2;
     const unsigned blocks = static_cast<unsigned>((threads + 255) / 256);
     hipLaunchKernelGGL(solid_mask_raster, dim3(blocks), dim3(256), 0, s, pts, faces, n_faces, value, Ytab, im, mask,
-                       lanes_log2);
+                       lanes_log2, only_across_border ? 1 : 0);
 }
 
 }  // namespace c5

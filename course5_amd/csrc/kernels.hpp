@@ -84,7 +84,8 @@ void launch_transform_aos(hipStream_t s, const double* in, double* out, int64_t 
                           const RotationList& R);
 void launch_solid_mask_raster(hipStream_t s, const double* pts, const int4* faces, int64_t n_faces,
                               uint32_t value, const double* Ytab, const ImageParams& im, uint32_t* mask,
-                              int lanes_per_face);  // power of two, 1..64: threads sharing the rows of one face
+                              int lanes_per_face,  // power of two, 1..64: threads sharing the rows of one face
+                              bool only_across_border = false);  // leave out faces a pixel inside the domain on every side
 
 // bin-sort-resolve (exact_kernels.hip): the reference's algorithm on the GPU
 void launch_bin_count(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,

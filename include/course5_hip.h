@@ -192,6 +192,12 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  never rotates, main.cpp:116; in a -D sweep only the lobe moves) is rastered once into a mask of its
  *                  own, which later frames lay over theirs; 0: every solid is transformed and rastered every frame.
  *                  Same masks either way.
+ *   "solid_interior_faces"  0 (default): a face of a solid with a cell of non-zero volume on either side is not rastered: the
+ *                  mask is the union over all faces (plane.cpp:130-131 -> line.cpp:246-249), and a ray through such a face
+ *                  also meets a face with nothing behind it — the three fan faces of every cell of the reference's
+ *                  centre-fan solids (object3d_base.cpp:152-193).  Only where get_pixel_by_x/_y's clamp (plane.cpp:194-212)
+ *                  has no hand in the face's pixels: an interior face within a pixel of a border, or beyond it, is kept.
+ *                  1 (testing): every unique face is rastered.  Same masks, bit for bit.
  *   "overlap_setup" 1: entry lists and solid mask are built on a side stream while build_records
  *                  runs (only when "stage_timing" is 0).  Default 0: measured no faster.
  *   "pipeline"     1: two frame slots; the per-view setup of frame k + 1 runs on a second stream while

@@ -18,9 +18,12 @@ ctx.upload_grid(xyz, c, a, q)
 ctx.set_image(2400, 1800, mg.REFERENCE_BOUNDS)
 rots = mg.view_rotations(0.1, 0.07)
 ctx.set_view(rots)
-for which in ("lobe", "sphere", "both"):
+ctx.set_option("solid_cache", 0)
+for interior in (0, 1, 0, 1):
+  ctx.set_option("solid_interior_faces", interior)
+  for which in ("lobe", "sphere", "both"):
     ctx.set_solid(0, solids[0] if which != "sphere" else np.zeros((0, 12))); ctx.set_solid_view(0, np.vstack([[1.0, 0.0, 1.0], rots]))
     ctx.set_solid(1, solids[1] if which != "lobe" else np.zeros((0, 12))); ctx.set_solid_view(1, np.zeros((0, 3)))
-    for i in range(4):
+    for i in range(6):
         img = ctx.render(); st = ctx.stats()
-    print(which, "ms_solids", round(st["ms_solids"], 3), "solid px", st["solid_pixels"], "total", round(st["ms_total"], 3))
+    print("interior faces rastered" if interior else "interior faces skipped ", which, "ms_solids", round(st["ms_solids"], 3), "solid px", st["solid_pixels"], "total", round(st["ms_total"], 3), flush=True)
