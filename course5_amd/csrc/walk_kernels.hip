@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
     // the wave-uniform iteration count IS the step count of every lane still walking: the guard
     // against malformed grids (never spin) is one scalar compare per iteration.
 #if C5_WALK_STAMPS
-    const bool stamping_ = (blockIdx.x & 63u) == 5u;  // wave-uniform
+    const bool stamping_ = (blockIdx.x % 67u) == 5u;  // wave-uniform; a stride that visits every XCD (blockIdx & 7) in turn
     const unsigned long long trace_begin_ = __builtin_amdgcn_s_memrealtime();
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned stat_runs = 0, stat_distinct = 0, stat_iters = 0, stat_lanes = 0;
