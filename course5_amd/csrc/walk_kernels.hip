@@ -382,7 +382,7 @@ constexpr int kSlotStride = C5_SLOT_STRIDE;
 using V2 = double __attribute__((ext_vector_type(2)));  // 16 bytes as one SSA value (never an alloca)
 __device__ __forceinline__ D2 as_d2(V2 v) { return D2{v.x, v.y}; }
 
-// Optional in-kernel phase clock (build with -DC5_WALK_STAMPS=1; scripts/stamp_walk.py): ONE WAVEFRONT IN 64 sums, per
+// Optional in-kernel phase clock (build with -DC5_WALK_STAMPS=1; scripts/stamp_walk.py): ONE WAVEFRONT IN 67 (every XCD in turn) sums, per
 // phase of a step, the shader cycles between stamps (s_memtime; tick = shader cycle) and lane 0 adds them to
 // g_walk_stamps; the other 63 run the product's instruction stream, so that the sampled wavefronts see the memory
 // system, the LDS and the issue ports as loaded as the product's do.  (Stamping every wavefront — the round-2 build —

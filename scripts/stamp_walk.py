@@ -3,7 +3,7 @@
     scripts/build_variant.sh stamps -DC5_WALK_STAMPS=1
     C5_LIB=course5_amd/libcourse5_hip_stamps.so python scripts/stamp_walk.py [round-tag]   -> profiles/<tag>_walk_phases.md
 
-One wavefront in 64 sums, per phase of a step, the s_memtime ticks (= shader cycles, MI355X_MICROARCH.md) between
+One wavefront in 67 (a stride that visits every XCD) sums, per phase of a step, the s_memtime ticks (= shader cycles, MI355X_MICROARCH.md) between
 stamps; it drains vmcnt / lgkmcnt at the two stamps that end a phase of waiting, so its split is exact; the other 63
 run the product's instruction stream, so the sampled wavefronts see the machine as loaded as the product does.
 """
@@ -57,7 +57,7 @@ for stage, label in ((2, "LDS-DMA staging (default)"), (1, "staged through vecto
     tot = sum(v[:5])
     steps = max(v[12], 1)
     lines += [f"## lds_stage {stage}: {label}", "",
-              f"walk {st['ms_walk']:.3f} ms (stamped build: one wavefront in 64 stamps), {st['steps']} lane-steps in the frame; sampled: "
+              f"walk {st['ms_walk']:.3f} ms (stamped build: one wavefront in 67 stamps), {st['steps']} lane-steps in the frame; sampled: "
               f"{v[9]} wavefronts with rays, {v[12]} wavefront-steps ({v[13] / steps:.1f} walking lanes per step), loop "
               f"{v[8] / max(v[9], 1):.0f} cycles per wavefront, **{tot / steps:.0f} shader cycles per wavefront-step**", "",
               "| phase | cycles | share | cycles per wavefront-step |", "|---|---|---|---|"]
