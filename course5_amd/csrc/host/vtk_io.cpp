@@ -1,5 +1,7 @@
 #include "vtk_io.hpp"
 
+#include "fast_deflate.hpp"
+
 #include <algorithm>
 #include <cctype>
 #include <cmath>
@@ -426,10 +428,14 @@ void write_vti(const std::string& path, const float* image, int res_x, int res_y
                 packed_size[static_cast<size_t>(b)] = zero_block.size();
                 continue;
             }
-            uLongf cap = bound;
-            if (compress2(scratch + static_cast<size_t>(b) * bound, &cap, reinterpret_cast<const Bytef*>(vals),
-                          static_cast<uLong>(count * sizeof(double)), Z_BEST_SPEED) != Z_OK)
-                cap = 0;
+            // the known parse of widened floats (fast_deflate.cpp) - zlib's own level 1 for whatever it declines
+            uLongf cap = static_cast<uLongf>(c5::deflate_widened_doubles(vals, static_cast<size_t>(count), scratch + static_cast<size_t>(b) * bound, bound));
+            if (cap == 0) {
+                cap = bound;
+                if (compress2(scratch + static_cast<size_t>(b) * bound, &cap, reinterpret_cast<const Bytef*>(vals),
+                              static_cast<uLong>(count * sizeof(double)), Z_BEST_SPEED) != Z_OK)
+                    cap = 0;
+            }
             packed_size[static_cast<size_t>(b)] = cap;
         }
         std::vector<uint64_t> offset(n_blocks + 1, 0);

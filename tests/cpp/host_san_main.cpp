@@ -10,15 +10,19 @@
 //   host_san solids                         init_polar: Roche lobe + sphere, unique faces -> counts
 //   host_san oracle <scene.bin> <out.f32>   the CPU oracle on a dumped scene (see the pytest for the layout)
 //   host_san blocks <world> <base> <c0> <c1> ...  cost-balanced row blocks of the native multi-GPU host
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <iterator>
 #include <limits>
 #include <stdexcept>
 #include <string>
+#include <random>
+#include <zlib.h>
 #include <vector>
 
 #include "adjacency.hpp"
@@ -26,6 +30,7 @@
 #include "config.hpp"
 #include "row_blocks.hpp"
 #include "scene.hpp"
+#include "fast_deflate.hpp"
 #include "vtk_io.hpp"
 
 extern "C" int c5o_render(const double* xyz, int64_t n_pts, const int32_t* cell_vert, int64_t n_cells, const double* alpha,
@@ -85,6 +90,101 @@ int main(int argc, char** argv) try {
         colour_range(px.data(), w, h, 1, &lo, &hi);
         write_png(std::string(argv[2]) + ".png", px.data(), w, h, 1, lo, hi);
         std::printf("wrote %dx%d range %g %g\n", w, h, lo, hi);
+        return 0;
+    }
+    if (mode == "deflate") {
+        // fast_deflate.cpp against zlib's own inflate: blocks of widened floats of every kind (smooth, noisy, runs of one
+        // value, specials, short blocks), and doubles that are NOT widened floats (must be declined)
+        const int rounds = argc > 2 ? std::atoi(argv[2]) : 200;
+        std::mt19937 rng(12345);
+        std::vector<double> vals;
+        std::vector<unsigned char> packed, back;
+        size_t total_in = 0, total_out = 0, total_zlib = 0;
+        for (int r = 0; r < rounds; ++r) {
+            const size_t n = (r % 7 == 0) ? 2 + rng() % 40 : (r % 5 == 0 ? 4096 : 1 + rng() % 4096);
+            vals.resize(n);
+            const int kind = r % 6;
+            float walk = 0.0f;
+            for (size_t i = 0; i < n; ++i) {
+                float v;
+                switch (kind) {
+                case 0: v = std::ldexp(static_cast<float>(rng() & 0xFFFFFF), -20 - static_cast<int>(rng() % 8)); break;       // noisy mantissas
+                case 1: walk += 0.01f * static_cast<float>(static_cast<int>(rng() % 200) - 100); v = walk; break;           // smooth
+                case 2: v = (rng() % 9 == 0) ? static_cast<float>(rng() % 5) : 0.0f; break;                                  // mostly zeros
+                case 3: v = (i / 37 % 2) ? std::numeric_limits<float>::quiet_NaN() : 7.5f; break;                            // runs
+                case 4: { uint32_t b = rng(); std::memcpy(&v, &b, 4); break; }                                               // any bit pattern (NaNs, denormals, infinities)
+                default: v = (i % 3 == 0) ? -0.0f : (i % 3 == 1 ? std::numeric_limits<float>::infinity() : 1e-42f); break;
+                }
+                vals[i] = static_cast<double>(v);
+            }
+            const size_t cap = compressBound(static_cast<uLong>(8 * n));
+            packed.assign(cap, 0xAB);
+            const size_t sz = c5::deflate_widened_doubles(vals.data(), n, packed.data(), cap);
+            if (n < 2) {
+                if (sz != 0) throw std::runtime_error("a single value must be declined");
+                continue;
+            }
+            if (sz == 0) {
+                // (a short block may not hold the code tables within compressBound, random bits may not compress: allowed)
+                if (kind != 4 && kind != 0 && n >= 64) throw std::runtime_error("declined a block it should take, kind " + std::to_string(kind));
+                continue;
+            }
+            back.assign(8 * n, 0);
+            uLongf got = static_cast<uLongf>(back.size());
+            const int rc = uncompress(back.data(), &got, packed.data(), static_cast<uLong>(sz));
+            if (rc != Z_OK || got != 8 * n || std::memcmp(back.data(), vals.data(), 8 * n) != 0)
+                throw std::runtime_error("round trip failed: rc " + std::to_string(rc) + " kind " + std::to_string(kind) + " n " + std::to_string(n));
+            uLongf zs = static_cast<uLongf>(cap);
+            std::vector<unsigned char> z(cap);
+            compress2(z.data(), &zs, reinterpret_cast<const Bytef*>(vals.data()), static_cast<uLong>(8 * n), Z_BEST_SPEED);
+            total_in += 8 * n;
+            total_out += sz;
+            total_zlib += zs;
+        }
+        // not widened floats: declined
+        std::vector<double> other(100);
+        for (size_t i = 0; i < other.size(); ++i) other[i] = 1.0 / (3.0 + static_cast<double>(i));
+        std::vector<unsigned char> o(4096);
+        if (c5::deflate_widened_doubles(other.data(), other.size(), o.data(), o.size()) != 0) throw std::runtime_error("took doubles that are not widened floats");
+        // a buffer that is too small: declined, nothing written past it
+        std::vector<double> big(4096, 0.0);
+        for (size_t i = 0; i < big.size(); ++i) big[i] = static_cast<double>(static_cast<float>(rng()) * 1e-3f);
+        std::vector<unsigned char> small(1000 + 16, 0xCD);
+        if (c5::deflate_widened_doubles(big.data(), big.size(), small.data(), 1000) != 0) throw std::runtime_error("claimed to fit 1000 bytes");
+        for (size_t i = 1000; i < small.size(); ++i)
+            if (small[i] != 0xCD) throw std::runtime_error("wrote past the end of its buffer");
+        std::printf("deflate ok: %zu bytes in, %zu out (zlib level 1: %zu)\n", total_in, total_out, total_zlib);
+        return 0;
+    }
+    if (mode == "deflate_file") {  // raw float32 file: sizes and single-thread times of both compressors, 32 KB blocks of doubles
+        if (argc < 3) throw std::runtime_error("deflate_file: path");
+        std::ifstream f(argv[2], std::ios::binary);
+        std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        const size_t n = raw.size() / 4;
+        std::vector<double> vals(n);
+        for (size_t i = 0; i < n; ++i) {
+            float v;
+            std::memcpy(&v, raw.data() + 4 * i, 4);
+            vals[i] = static_cast<double>(v);
+        }
+        const size_t cap = compressBound(32768);
+        std::vector<unsigned char> out(cap);
+        size_t fast = 0, slow = 0, declined = 0;
+        auto t0 = std::chrono::steady_clock::now();
+        for (size_t i = 0; i < n; i += 4096) {
+            const size_t sz = c5::deflate_widened_doubles(vals.data() + i, std::min<size_t>(4096, n - i), out.data(), cap);
+            fast += sz;
+            declined += sz == 0;
+        }
+        auto t1 = std::chrono::steady_clock::now();
+        for (size_t i = 0; i < n; i += 4096) {
+            uLongf zs = static_cast<uLongf>(cap);
+            compress2(out.data(), &zs, reinterpret_cast<const Bytef*>(vals.data() + i), static_cast<uLong>(8 * std::min<size_t>(4096, n - i)), Z_BEST_SPEED);
+            slow += zs;
+        }
+        auto t2 = std::chrono::steady_clock::now();
+        std::printf("%zu doubles: fast %zu bytes in %.1f ms (%zu blocks declined), zlib level 1 %zu bytes in %.1f ms\n", n, fast,
+                    std::chrono::duration<double, std::milli>(t1 - t0).count(), declined, slow, std::chrono::duration<double, std::milli>(t2 - t1).count());
         return 0;
     }
     if (mode == "cli") {
