@@ -187,6 +187,22 @@ int main(int argc, char** argv) try {
                     std::chrono::duration<double, std::milli>(t1 - t0).count(), declined, slow, std::chrono::duration<double, std::milli>(t2 - t1).count());
         return 0;
     }
+    if (mode == "vti_time") {  // raw float32 image file, w, h, repeats: time of write_vti (zlib .vti) per call
+        if (argc < 6) throw std::runtime_error("vti_time: in.f32 w h repeats");
+        const int w = std::atoi(argv[3]), h = std::atoi(argv[4]), reps = std::atoi(argv[5]);
+        std::ifstream f(argv[2], std::ios::binary);
+        std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        if (raw.size() != static_cast<size_t>(w) * h * 8) throw std::runtime_error("vti_time: size");
+        const std::string out = std::string(argv[2]) + ".vti";
+        write_vti(out, reinterpret_cast<const float*>(raw.data()), w, h, true);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < reps; ++r) write_vti(out, reinterpret_cast<const float*>(raw.data()), w, h, true);
+        const auto t1 = std::chrono::steady_clock::now();
+        std::ifstream g(out, std::ios::binary | std::ios::ate);
+        std::printf("write_vti %dx%d: %.2f ms per call, file %lld bytes\n", w, h, std::chrono::duration<double, std::milli>(t1 - t0).count() / reps,
+                    static_cast<long long>(g.tellg()));
+        return 0;
+    }
     if (mode == "cli") {
         const bool go = program_options(argc - 1, argv + 1, std::cout);
         const render_config& c = app::instance().config;
