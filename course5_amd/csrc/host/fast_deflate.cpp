@@ -10,8 +10,6 @@
 // matches this input does not have; this spends about one.
 #include "fast_deflate.hpp"
 
-#include <zlib.h>
-
 #include <algorithm>
 #include <cstring>
 
@@ -139,23 +137,28 @@ struct BitWriter {
     }
 };
 
-}  // namespace
-
-size_t deflate_widened_doubles(const double* vals, size_t count, unsigned char* out, size_t cap) {
+// word(i): the i-th value's eight bytes as a little-endian word (byte k = bits 8k ... 8k + 7)
+template <class Word>
+size_t encode(Word word, size_t count, unsigned char* out, size_t cap) {
     if (count < 2 || count > (size_t{1} << 24) || cap < 64) return 0;
-    const unsigned char* bytes = reinterpret_cast<const unsigned char*>(vals);
-    auto word = [&](size_t i) {
-        uint64_t w;
-        std::memcpy(&w, bytes + 8 * i, 8);
-        return w;
-    };
-    // pass 1: is it what it should be, and how often does every symbol occur
+    auto byte_of = [](uint64_t w, int b) { return static_cast<unsigned>((w >> (8 * b)) & 0xFFu); };
+    // pass 1: is it what it should be, how often does every symbol occur, and the stream's Adler-32 (RFC 1950: of the
+    // uncompressed bytes; the three zero bytes of a value add nothing to s1 and 3 s1 to s2)
     uint32_t f_lit[288] = {0}, f_dist[30] = {0};
+    uint64_t s1 = 1, s2 = 0;  // (no overflow below 2^24 values: s1 < 2^35, s2 < 2^62)
+    auto adler_value = [&](uint64_t w) {
+        s2 += 3 * s1;
+        for (int b = 3; b < 8; ++b) {
+            s1 += byte_of(w, b);
+            s2 += s1;
+        }
+    };
     const LengthCode run_full = length_code(256), three = length_code(3);
     {
         uint64_t prev = word(0);
         if (prev & 0xFFFFFFull) return 0;
-        for (int b = 0; b < 8; ++b) ++f_lit[bytes[b]];
+        for (int b = 0; b < 8; ++b) ++f_lit[byte_of(prev, b)];
+        adler_value(prev);
         size_t run = 0;
         auto flush = [&]() {
             size_t left = 8 * run;
@@ -173,6 +176,7 @@ size_t deflate_widened_doubles(const double* vals, size_t count, unsigned char* 
         for (size_t i = 1; i < count; ++i) {
             const uint64_t w = word(i);
             if (w & 0xFFFFFFull) return 0;  // not a widened float: the caller's general compressor takes it
+            adler_value(w);
             if (w == prev) {
                 ++run;
                 continue;
@@ -180,7 +184,7 @@ size_t deflate_widened_doubles(const double* vals, size_t count, unsigned char* 
             if (run) flush();
             ++f_lit[three.code];
             ++f_dist[5];
-            for (int b = 3; b < 8; ++b) ++f_lit[bytes[8 * i + b]];
+            for (int b = 3; b < 8; ++b) ++f_lit[byte_of(w, b)];
             prev = w;
         }
         if (run) flush();
@@ -266,7 +270,7 @@ size_t deflate_widened_doubles(const double* vals, size_t count, unsigned char* 
     };
     {
         uint64_t prev = word(0);
-        for (int b = 0; b < 8; ++b) w.put(c_lit[bytes[b]], l_lit[bytes[b]]);
+        for (int b = 0; b < 8; ++b) w.put(c_lit[byte_of(prev, b)], l_lit[byte_of(prev, b)]);
         size_t run = 0;
         auto flush = [&]() {
             size_t left = 8 * run;
@@ -282,7 +286,7 @@ size_t deflate_widened_doubles(const double* vals, size_t count, unsigned char* 
             }
             if (run) flush();
             // the three zero bytes as a match, the five others as literals: at most 13 + 5 x 15 bits, in three puts
-            const unsigned char* q = bytes + 8 * i;
+            const unsigned q[8] = {0, 0, 0, byte_of(v, 3), byte_of(v, 4), byte_of(v, 5), byte_of(v, 6), byte_of(v, 7)};
             w.put(c_lit[three.code], l_lit[three.code]);
             w.put(static_cast<uint32_t>(c_dist[5]) | 2u, 2);  // distance code (one bit: 0) + extra bit 1
             w.put(static_cast<uint32_t>(c_lit[q[3]]) | (static_cast<uint32_t>(c_lit[q[4]]) << l_lit[q[3]]), l_lit[q[3]] + l_lit[q[4]]);
@@ -295,12 +299,36 @@ size_t deflate_widened_doubles(const double* vals, size_t count, unsigned char* 
     w.put(c_lit[256], l_lit[256]);
     w.finish();
     if (!w.ok) return 0;
-    const uLong adler = adler32(adler32(0L, Z_NULL, 0), bytes, static_cast<uInt>(8 * count));
+    const uint32_t adler = (static_cast<uint32_t>(s2 % 65521u) << 16) | static_cast<uint32_t>(s1 % 65521u);
     w.p[0] = static_cast<unsigned char>(adler >> 24);
     w.p[1] = static_cast<unsigned char>(adler >> 16);
     w.p[2] = static_cast<unsigned char>(adler >> 8);
     w.p[3] = static_cast<unsigned char>(adler);
     return static_cast<size_t>(w.p + 4 - out);
+}
+
+}  // namespace
+
+size_t deflate_widened_doubles(const double* vals, size_t count, unsigned char* out, size_t cap) {
+    const unsigned char* bytes = reinterpret_cast<const unsigned char*>(vals);
+    return encode(
+        [bytes](size_t i) {
+            uint64_t w;
+            std::memcpy(&w, bytes + 8 * i, 8);
+            return w;
+        },
+        count, out, cap);
+}
+
+size_t deflate_floats_as_doubles(const float* vals, size_t count, unsigned char* out, size_t cap) {
+    return encode(
+        [vals](size_t i) {
+            const double d = static_cast<double>(vals[i]);  // (exact: every float is a double)
+            uint64_t w;
+            std::memcpy(&w, &d, 8);
+            return w;
+        },
+        count, out, cap);
 }
 
 }  // namespace c5

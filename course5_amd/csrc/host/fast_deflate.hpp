@@ -8,4 +8,6 @@ namespace c5 {
 // made of widened floats (some value has a bit set among its low 24), has fewer than two values, or does not fit cap:
 // the caller then uses the general compressor.
 size_t deflate_widened_doubles(const double* vals, size_t count, unsigned char* out, size_t cap);
+// The same stream, straight from the floats (what static_cast<double> makes of them), without the array of doubles.
+size_t deflate_floats_as_doubles(const float* vals, size_t count, unsigned char* out, size_t cap);
 }  // namespace c5

@@ -419,22 +419,23 @@ void write_vti(const std::string& path, const float* image, int res_x, int res_y
         for (int64_t b = 0; b < nb; ++b) {
             const uint64_t first = static_cast<uint64_t>(b) * kBlock / sizeof(double);
             const uint64_t count = std::min<uint64_t>(kBlock / sizeof(double), n_values - first);
-            double vals[kBlock / sizeof(double)];
             uint32_t any = 0;  // +0.0f only (a -0.0f or a NaN has bits set)
             for (uint64_t k = 0; k < count; ++k) {
                 uint32_t bits;
                 std::memcpy(&bits, image + first + k, sizeof bits);
                 any |= bits;
-                vals[k] = static_cast<double>(image[first + k]);
             }
             if (any == 0 && count == kBlock / sizeof(double) && !zero_block.empty()) {
                 std::memcpy(scratch + static_cast<size_t>(b) * bound, zero_block.data(), zero_block.size());
                 packed_size[static_cast<size_t>(b)] = zero_block.size();
                 continue;
             }
-            // the known parse of widened floats (fast_deflate.cpp) - zlib's own level 1 for whatever it declines
-            uLongf cap = static_cast<uLongf>(c5::deflate_widened_doubles(vals, static_cast<size_t>(count), scratch + static_cast<size_t>(b) * bound, bound));
+            // the known parse of widened floats, straight from the floats (fast_deflate.cpp) - zlib's own level 1 for
+            // whatever it declines (a last block too short to carry its code tables)
+            uLongf cap = static_cast<uLongf>(c5::deflate_floats_as_doubles(image + first, static_cast<size_t>(count), scratch + static_cast<size_t>(b) * bound, bound));
             if (cap == 0) {
+                double vals[kBlock / sizeof(double)];
+                for (uint64_t k = 0; k < count; ++k) vals[k] = static_cast<double>(image[first + k]);
                 cap = bound;
                 if (compress2(scratch + static_cast<size_t>(b) * bound, &cap, reinterpret_cast<const Bytef*>(vals),
                               static_cast<uLong>(count * sizeof(double)), Z_BEST_SPEED) != Z_OK)
