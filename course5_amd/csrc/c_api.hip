@@ -109,6 +109,13 @@ struct FrameSlot {
     long long sb_key = -1;  // the tiling they belong to (-1: not collected)
     int sb_n = 0;
     DeviceBuffer geo, opt32, z0;  // "precision" 1: compact records (allocated on first use)
+    // "view_cache": the per-view data in this slot (transformed vertices, records, entry lists) were built for ...
+    uint64_t setup_epoch = 0;     // ... this state of the context (c5_context::setup_epoch; 0: nothing built)
+    c5::RotationList setup_view{};
+    double setup_limit = 0.0;
+    int setup_order = 0;
+    bool setup_kept = false;      // ... and the walk that used them left the entry heads in place
+    bool setup_reused = false;    // the last frame enqueued into this slot skipped the per-view setup
     int64_t entry_capacity = 0;
     bool head_clean = false;  // the per-pixel entry heads are all zero (the walk kernels leave them so)
     bool optics_valid = false;  // opt[] holds the optics of the current scalars for (optics_limit, optics_order)
@@ -147,6 +154,8 @@ struct c5_context {
     int stage_slots = 0;    // "stage_slots": 0 = chosen per frame from rays_per_cell, or 14 / 21
     double rays_per_cell = 0.0;  // of the last finished frame (0: none yet)
     int solid_cache = 1;    // a solid unchanged since the frame before is not rastered again (enqueue_solids)
+    int view_cache = 1;     // "view_cache": a frame with the view of the two before it reuses their per-view data (enqueue_frame)
+    uint64_t setup_epoch = 1;  // bumped by everything but the view, the alpha limit and the solids that the per-view data depend on
     int solid_interior_faces = 0;  // 1: interior faces are rastered too (they cover nothing the others do not; testing)
     int overlap_setup = 0;  // measured: 1.27 vs 1.26 ms/frame, the side stream buys nothing
     DeviceBuffer px, py, pz, cell_vert, cell_adj, alpha, q, bface;
@@ -298,6 +307,7 @@ int ensure_image_buffers(c5_context* ctx) {
         if (fs.entry_capacity < n_px / 4 + 8192) {
             fs.entry_capacity = n_px / 4 + 8192;
             C5_HIP(ctx, fs.pool.ensure(static_cast<size_t>(fs.entry_capacity) * sizeof(c5::Entry)));
+            ++ctx->setup_epoch;
         }
     }
     return C5_OK;
@@ -542,10 +552,30 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     }
     fs.sb_key = sb_key;
     fs.sb_n = n_sb;
-    c5::launch_transform_soa(s, g.px, g.py, g.pz, g.vx, g.vy, g.vz, g.n_pts, ctx->view,
-                             fs.counters.as<c5::FrameCounters>(), sb, n_sb);
-    C5_HIP(ctx, mark(1, s));
     const bool bin_sort = ctx->algorithm == 1 || !ctx->grid_conforming;
+    // "view_cache" (the persistent device grid of a -D sweep: only the donor turns, main.cpp:112-116): transformed
+    // vertices, records and entry lists depend on the grid, the image, the view, the alpha limit and the order - a frame
+    // that has all of them in common with the frame before reuses them.  The walk normally hands the entry heads back
+    // cleared, so it takes TWO frames with the same view in a row before there is something to reuse: the second one
+    // builds everything once more and tells its walk to leave the heads alone; the third and later ones skip the
+    // per-view setup.  A sweep whose view changes every frame never pays for any of this.
+    const bool cacheable = ctx->view_cache && !ctx->pipeline && !bin_sort && !ctx->fuse_setup && !ctx->overlap_setup &&
+                           !(ctx->precision == 1 && c5::mixed_precision_fits(ctx->n_cells, im)) && g.n_cells > 0;
+    const bool same_view = cacheable && fs.setup_epoch == ctx->setup_epoch && same_rotations(fs.setup_view, ctx->view) &&
+                           fs.setup_limit == ctx->alpha_limit && fs.setup_order == ctx->order;
+    const bool reuse = same_view && fs.setup_kept;
+    fs.setup_reused = reuse;
+    fs.setup_epoch = cacheable ? ctx->setup_epoch : 0;
+    fs.setup_view = ctx->view;
+    fs.setup_limit = ctx->alpha_limit;
+    fs.setup_order = ctx->order;
+    fs.setup_kept = same_view;  // (this frame's walk leaves the heads in place)
+    if (reuse)
+        c5::launch_clear_walk_counters(s, fs.counters.as<c5::FrameCounters>(), sb, n_sb);
+    else
+        c5::launch_transform_soa(s, g.px, g.py, g.pz, g.vx, g.vy, g.vz, g.n_pts, ctx->view,
+                                 fs.counters.as<c5::FrameCounters>(), sb, n_sb);
+    C5_HIP(ctx, mark(1, s));
     if (bin_sort) return enqueue_bin_sort(ctx, fs, g, slot_id, out_dev, s, main_s, timed);
     // (a1, a10, a13 constants) per-cell records on the setup stream; the boundary entry lists and the
     // solid mask need only the transformed vertices, so they run beside it on a side stream (they are
@@ -581,7 +611,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
                                        optics_stale);
         fs.optics32_valid = true;
         fs.optics32_limit = ctx->alpha_limit;
-    } else if (!(ctx->fuse_setup && !side && g.n_cells > 0)) {
+    } else if (!(ctx->fuse_setup && !side && g.n_cells > 0) && !reuse) {
         // (a cell's optics ride in its record since round 3 — one line per cell and step — and are rewritten with it)
         c5::launch_build_records(s, g, ctx->alpha_limit, ctx->order);
     }
@@ -594,7 +624,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     const double key_slack = !ctx->entry_key ? -1.0
                              : (mixed ? c5::kEntryKeySlackMixed * ctx->grid_diagonal + 0x1p-22 * ctx->coord_max
                                       : c5::kEntryKeySlack * ctx->grid_diagonal + 0x1p-40 * ctx->coord_max);
-    if (!fs.head_clean) C5_HIP(ctx, hipMemsetAsync(fs.head.ptr, 0, static_cast<size_t>(padded) * sizeof(c5::EntryHead), e));
+    if (!fs.head_clean && !reuse) C5_HIP(ctx, hipMemsetAsync(fs.head.ptr, 0, static_cast<size_t>(padded) * sizeof(c5::EntryHead), e));
     fs.head_clean = false;
     if (fused) {
         // records and entry lists as ONE launch of interleaved workgroups ("fuse_setup"; ms_records then holds the
@@ -603,7 +633,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
                                fs.head.as<c5::EntryHead>(), fs.first.as<c5::Entry>(), fs.pool.as<c5::Entry>(), fs.entry_capacity,
                                fs.counters.as<c5::FrameCounters>(), ctx->sticky.as<unsigned>(), ctx->order != 0, key_slack);
         C5_HIP(ctx, mark(2, s));
-    } else if (g.n_cells > 0) {
+    } else if (g.n_cells > 0 && !reuse) {
         c5::launch_entry_lists(e, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im, fs.head.as<c5::EntryHead>(),
                                fs.first.as<c5::Entry>(), fs.pool.as<c5::Entry>(), fs.entry_capacity,
                                fs.counters.as<c5::FrameCounters>(), ctx->sticky.as<unsigned>(), ctx->order != 0,
@@ -655,6 +685,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
         if (!(a_max >= 0.0)) a_max = ctx->alpha_top;  // (a NaN limit clamps nothing: line.cpp:216-218)
         wp.small_exp_only = (a_max * ctx->edge_max < 0.125) ? 1 : 0;
     }
+    wp.keep_entries = fs.setup_kept ? 1 : 0;
     wp.row_cost = nullptr;
     wp.sb_cost = sb;
     wp.n_sb_rows = 0;
@@ -692,7 +723,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
         c5::launch_walk_mixed(main_s, wp, ctx->tile_shape);
     else
         c5::launch_walk(main_s, wp, ctx->tile_shape);
-    fs.head_clean = true;  // stream order: every pixel's head is zero again once the walk has run
+    fs.head_clean = !wp.keep_entries;  // stream order: every pixel's head is zero again once the walk has run
     if (ev_slot >= 0) C5_HIP(ctx, hipEventRecord(ctx->walk_b[ev_slot], main_s));
     C5_HIP(ctx, mark(5, main_s));
     C5_HIP(ctx, hipGetLastError());
@@ -786,6 +817,8 @@ int finish_frame(c5_context* ctx) {
         float* dst[5] = {&st.ms_transform, &st.ms_records, &st.ms_entries, &st.ms_solids, &st.ms_walk};
         for (int k = 0; k < 5; ++k) C5_HIP(ctx, hipEventElapsedTime(dst[k], fs.ev[k], fs.ev[k + 1]));
         C5_HIP(ctx, hipEventElapsedTime(&st.ms_total, fs.ev[0], fs.ev[5]));
+        // a frame that reused the per-view data of the frames before it ("view_cache") ran none of the three: exactly 0
+        if (fs.setup_reused) st.ms_transform = st.ms_records = st.ms_entries = 0.0f;
     }
     // overflow entries this frame needed: handed out (a shard hands out min(asked, its part)) + refused
     int64_t handed = 0;
@@ -826,6 +859,7 @@ int finish_frame(c5_context* ctx) {
             if (o.entry_capacity >= want) continue;
             o.entry_capacity = want;
             C5_HIP(ctx, o.pool.ensure(static_cast<size_t>(want) * sizeof(c5::Entry)));
+            ++ctx->setup_epoch;  // (the entry lists lived in the old pool)
         }
     }
     if (too_small) {
@@ -990,6 +1024,7 @@ void c5_destroy(c5_context* ctx) {
 
 int c5_set_stream(c5_context* ctx, void* hip_stream) {
     if (!ctx) return fail(nullptr, C5_ERR_INVALID, "null context");
+    ++ctx->setup_epoch;  // whatever was built per view is stale ("view_cache")
     int rc = bind_device(ctx);
     if (rc) return rc;
     rc = wait_and_collect(ctx);
@@ -1003,6 +1038,7 @@ const char* c5_last_error(const c5_context* ctx) { return ctx ? ctx->error.c_str
 int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int32_t* cell_vert,
                    int64_t n_cells, const double* alpha, const double* q) {
     if (!ctx) return fail(nullptr, C5_ERR_INVALID, "null context");
+    ++ctx->setup_epoch;  // whatever was built per view is stale ("view_cache")
     if (n_pts < 0 || n_cells < 0) return fail(ctx, C5_ERR_INVALID, "negative size");
     if (n_cells > 0 && (!xyz || !cell_vert || !alpha || !q)) return fail(ctx, C5_ERR_INVALID, "null grid array");
     if (n_cells >= static_cast<int64_t>(c5::kNoCell))
@@ -1122,6 +1158,7 @@ int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int3
 
 int c5_update_scalars(c5_context* ctx, const double* alpha, const double* q, int64_t n_cells) {
     if (!ctx) return fail(nullptr, C5_ERR_INVALID, "null context");
+    ++ctx->setup_epoch;  // whatever was built per view is stale ("view_cache")
     if (n_cells != ctx->n_cells) return fail(ctx, C5_ERR_INVALID, "scalar count differs from the uploaded grid");
     if (n_cells > 0 && (!alpha || !q)) return fail(ctx, C5_ERR_INVALID, "null scalar array");
     int rc = bind_device(ctx);
@@ -1229,6 +1266,7 @@ int c5_set_solid(c5_context* ctx, int slot, const double* tets, int64_t n_tets, 
 
 int c5_set_image(c5_context* ctx, int res_x, int res_y, const double* bounds4) {
     if (!ctx) return fail(nullptr, C5_ERR_INVALID, "null context");
+    ++ctx->setup_epoch;  // whatever was built per view is stale ("view_cache")
     if (!bounds4) return fail(ctx, C5_ERR_INVALID, "plane initializer. wrong manual boundaries");  // plane.cpp:262-264
     if (res_x < 2 || res_y < 2) return fail(ctx, C5_ERR_INVALID, "critical error. empty plane");
     int rc = bind_device(ctx);
@@ -1269,6 +1307,7 @@ int c5_set_image(c5_context* ctx, int res_x, int res_y, const double* bounds4) {
 
 int c5_set_row_tiles(c5_context* ctx, int tile_rows, int rank, int world) {
     if (!ctx) return fail(nullptr, C5_ERR_INVALID, "null context");
+    ++ctx->setup_epoch;  // whatever was built per view is stale ("view_cache")
     if (world < 1 || rank < 0 || rank >= world) return fail(ctx, C5_ERR_INVALID, "bad rank/world %d/%d", rank, world);
     if (tile_rows < 0) return fail(ctx, C5_ERR_INVALID, "bad tile_rows");
     if (world > 1 && tile_rows == 0) return fail(ctx, C5_ERR_INVALID, "tile_rows must be > 0 when world > 1");
@@ -1288,6 +1327,7 @@ int c5_set_row_tiles(c5_context* ctx, int tile_rows, int rank, int world) {
 
 int c5_set_row_range(c5_context* ctx, int row_begin, int row_count) {
     if (!ctx) return fail(nullptr, C5_ERR_INVALID, "null context");
+    ++ctx->setup_epoch;  // whatever was built per view is stale ("view_cache")
     if (row_begin < 0 || row_count < -1) return fail(ctx, C5_ERR_INVALID, "bad row range");
     const int old_begin = ctx->cfg_row_begin, old_count = ctx->cfg_row_count;
     ctx->cfg_row_begin = row_begin;
@@ -1347,6 +1387,9 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit) {
 int c5_set_option(c5_context* ctx, const char* name, double value) {
     if (!ctx || !name) return fail(ctx, C5_ERR_INVALID, "null option");
     const std::string n(name);
+    // whatever was built per view is stale ("view_cache") - except after the switches callers flip from frame to frame,
+    // which the per-view data do not depend on
+    if (n != "row_costs" && n != "stage_timing" && n != "walk_timing") ++ctx->setup_epoch;
     if (n == "tile") {
         if (value < 0 || value > 3) return fail(ctx, C5_ERR_INVALID, "tile must be 0, 1, 2 or 3");
         ctx->tile_shape = static_cast<int>(value);
@@ -1376,6 +1419,8 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
     } else if (n == "solid_interior_faces") {
         ctx->solid_interior_faces = static_cast<int>(value) != 0;
         for (Solid& so : ctx->solids) so.own_mask_ready = false, so.unchanged_frames = 0, so.seen_generation = ~uint64_t{0};
+    } else if (n == "view_cache") {
+        ctx->view_cache = static_cast<int>(value) != 0;
     } else if (n == "solid_cache") {
         ctx->solid_cache = static_cast<int>(value) != 0;
         for (Solid& so : ctx->solids) so.own_mask_ready = false, so.unchanged_frames = 0, so.seen_generation = ~uint64_t{0};

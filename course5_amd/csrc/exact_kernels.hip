@@ -10,6 +10,7 @@
 //                        including the clamped pixel mapping (plane.cpp:194-212).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 
 #include "device_types.hpp"
@@ -508,6 +509,26 @@ void launch_resolve(hipStream_t s, const GridView& g, const ImageParams& im, con
 }
 
 size_t segment_bytes() { return sizeof(Segment); }
+
+__global__ __launch_bounds__(128) void clear_walk_counters(FrameCounters* __restrict__ counters, uint32_t* __restrict__ sb, int n_sb) {
+    const int i = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
+    if (sb && i < n_sb) sb[i] = 0u;
+    if (i < kCounterShards) {
+        FrameCounters& c = counters[i];
+        c.segments = 0;
+        c.steps = 0;
+        c.covered = 0;
+        c.solid_pixels = 0;
+        c.entries = 0;
+        c.walk_overflow = 0;
+        c.odd_pixels = 0;
+    }
+}
+
+void launch_clear_walk_counters(hipStream_t s, FrameCounters* counters, uint32_t* sb, int n_sb) {
+    const int n = std::max(kCounterShards, sb ? n_sb : 0);
+    hipLaunchKernelGGL(clear_walk_counters, dim3(static_cast<unsigned>((n + 127) / 128)), dim3(128), 0, s, counters, sb, n_sb);
+}
 
 void launch_transform_soa(hipStream_t s, const double* px, const double* py, const double* pz,
                           double* vx, double* vy, double* vz, int64_t n, const RotationList& R,

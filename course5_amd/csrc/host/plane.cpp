@@ -377,6 +377,9 @@ plane::plane(std::size_t res_x, std::size_t res_y, std::vector<object3d_base> ob
         check(c5_set_image(ctx, static_cast<int>(res_x), static_cast<int>(res_y), global_boundaries.data()), "c5_set_image", k);
         check(c5_set_alpha_limit(ctx, app::instance().config.limit_alpha_value), "c5_set_alpha_limit", k);  // line.cpp:204
         if (app::instance().config.reference_algorithm) check(c5_set_option(ctx, "algorithm", 1.0), "c5_set_option", k);
+        // --bench times frames as if each were a new one: no per-view data carried from frame to frame (a real sweep with
+        // a fixed view - the donor sweep -D, main.cpp:112-116 - keeps them: the library's "view_cache")
+        if (app::instance().config.bench > 0) check(c5_set_option(ctx, "view_cache", 0.0), "c5_set_option", k);
         // test hook: start from an overflow pool of this many records, so that the C5_RETRY handling of trace_rays
         // (frames in flight rendered again, in order, each with its own views) is exercised end to end
         if (const char* starve = std::getenv("C5_TEST_ENTRY_POOL"))

@@ -68,12 +68,18 @@ struct WalkParams {
     int32_t n_sb_rows;
     uint8_t sb_order[128];
     uint32_t* row_cost;         // [n_local_rows] segments per row of this frame, or nullptr
+    // 1: the walk leaves the per-pixel entry heads as they are (it normally hands them back cleared): the next frame has
+    // the same view and reuses the entry lists, the records and the transformed vertices (c_api.hip: "view_cache")
+    int32_t keep_entries;
     unsigned* sticky;           // [0] largest entry total, [1] rays over the step bound; reset by the host only
 };
 
 // exact_kernels.hip (-ffp-contract=off)
 // counters_to_clear: the frame's FrameCounters[kCounterShards], zeroed by the same launch (or nullptr)
 // sb_cost_to_clear: the walk's per-row costs (WalkParams::sb_cost), n_sb of them, cleared by the same launch
+// A frame that reuses the per-view data of the frame before: only what the walk adds to is cleared (the raster's part of
+// the counters - pool_used, entry_overflow - stays), and the walk's per-row costs
+void launch_clear_walk_counters(hipStream_t s, FrameCounters* counters, uint32_t* sb_cost_to_clear, int n_sb);
 void launch_transform_soa(hipStream_t s, const double* px, const double* py, const double* pz,
                           double* vx, double* vy, double* vz, int64_t n, const RotationList& R,
                           FrameCounters* counters_to_clear, uint32_t* sb_cost_to_clear = nullptr, int n_sb = 0);

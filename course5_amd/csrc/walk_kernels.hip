@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
             result.x = static_cast<float>(tau);  // plane.cpp:165
             result.y = static_cast<float>(I);    // plane.cpp:166
         }
-        __builtin_nontemporal_store(0ll, reinterpret_cast<long long*>(P.entry_head + lp));  // cleared for the next frame
+        if (!P.keep_entries) __builtin_nontemporal_store(0ll, reinterpret_cast<long long*>(P.entry_head + lp));  // cleared for the next frame
         __builtin_nontemporal_store(result.x, &P.out[lp].x);
         __builtin_nontemporal_store(result.y, &P.out[lp].y);
     }
@@ -886,7 +886,7 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
         }
         // every pixel hands its entry head back cleared: the next frame's raster needs no memset
         n_entries = static_cast<unsigned>(load_entry_head(P.entry_head + lp).count);
-        if (n_entries) __builtin_nontemporal_store(0ll, reinterpret_cast<long long*>(P.entry_head + lp));
+        if (n_entries && !P.keep_entries) __builtin_nontemporal_store(0ll, reinterpret_cast<long long*>(P.entry_head + lp));
         __builtin_nontemporal_store(result.x, &P.out[lp].x);
         __builtin_nontemporal_store(result.y, &P.out[lp].y);
     }

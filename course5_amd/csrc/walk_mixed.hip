@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) void w
             is_solid = 1;
         }
         n_entries = static_cast<unsigned>(load_entry_head(P.entry_head + lp).count);
-        if (n_entries) __builtin_nontemporal_store(0ll, reinterpret_cast<long long*>(P.entry_head + lp));
+        if (n_entries && !P.keep_entries) __builtin_nontemporal_store(0ll, reinterpret_cast<long long*>(P.entry_head + lp));
         __builtin_nontemporal_store(result.x, &P.out[lp].x);
         __builtin_nontemporal_store(result.y, &P.out[lp].y);
     }

@@ -76,7 +76,8 @@ typedef struct c5_stats {
     int32_t walk_overflow;   /* rays that hit the step bound */
     int32_t entry_overflow;  /* the overflow pool was too small for this frame (C5_RETRY) */
     /* GPU time of the last frame per stage, milliseconds (HIP events on the context stream) */
-    float ms_transform;      /* view transform                     (a2) */
+    float ms_transform;      /* view transform                     (a2); this and the next two are exactly 0 for a frame that
+                              * reused the per-view data of the frames before it (option "view_cache") */
     float ms_records;        /* per-cell walk records              (a1, a10) */
     float ms_entries;        /* boundary entry raster, one pass    (a6/a7 for boundary faces) */
     float ms_solids;         /* solid mask raster                  (a6, a9) */
@@ -198,6 +199,15 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  centre-fan solids (object3d_base.cpp:152-193).  Only where get_pixel_by_x/_y's clamp (plane.cpp:194-212)
  *                  has no hand in the face's pixels: an interior face within a pixel of a border, or beyond it, is kept.
  *                  1 (testing): every unique face is rastered.  Same masks, bit for bit.
+ *   "view_cache"   1 (default): a frame whose grid, scalars, image, rows, view, alpha limit and order are those of the TWO frames
+ *                  before it reuses their per-view data — transformed vertices, cell records, boundary entry lists — instead
+ *                  of building them again: the persistent device grid of a donor sweep (main.cpp:112-116: only the lobe
+ *                  turns).  The second frame of such a run builds everything once more and tells its walk to leave the
+ *                  per-pixel entry heads in place (the walk normally hands them back cleared); the third and later ones
+ *                  skip the three setup launches (c5_stats: their ms_transform / ms_records / ms_entries are exactly 0).
+ *                  Anything the data depend on makes them stale: c5_upload_grid, c5_update_scalars, c5_set_image, the row
+ *                  setters, c5_set_stream, any option but "row_costs" / "stage_timing" / "walk_timing", a grown entry pool.
+ *                  A sweep whose view changes every frame never pays for it.  0: every frame builds its own.  Same results.
  *   "overlap_setup" 1: entry lists and solid mask are built on a side stream while build_records
  *                  runs (only when "stage_timing" is 0).  Default 0: measured no faster.
  *   "pipeline"     1: two frame slots; the per-view setup of frame k + 1 runs on a second stream while

@@ -1,0 +1,140 @@
+"""Option "view_cache" (default on): a frame whose grid, image, view, alpha limit and order are those of the TWO frames
+before it reuses their per-view data - transformed vertices, cell records, boundary entry lists - instead of building
+them again (the persistent device grid of a donor sweep: only the lobe turns, main.cpp:112-116).  Every way the cache
+can go stale is walked through; every frame must equal the same frame rendered with the cache off, bit for bit and
+statistic for statistic, and the frames that should reuse must really skip the setup kernels."""
+import numpy as np
+import pytest
+
+from course5_amd import meshgen as mg
+
+pytestmark = pytest.mark.gpu
+PI = float(np.pi)
+KEYS = ("segments", "covered_pixels", "solid_pixels", "entries", "pool_entries", "steps", "walk_overflow")
+
+
+@pytest.fixture(autouse=True)
+def _reset(gpu_ctx):
+    gpu_ctx.set_option("view_cache", 1)
+    gpu_ctx.set_option("stage_timing", 1)
+    gpu_ctx.set_option("integration", 0)
+    gpu_ctx.set_row_tiles(0, 0, 1)
+    gpu_ctx.set_row_range(0, -1)
+    yield
+    for k in range(8):
+        gpu_ctx.set_solid(k, np.zeros((0, 12)))
+    gpu_ctx.set_option("view_cache", 1)
+    gpu_ctx.set_option("integration", 0)
+    gpu_ctx.set_row_range(0, -1)
+
+
+def _frames(ctx, n):
+    out = []
+    for _ in range(n):
+        img = ctx.render().copy()
+        out.append((img, ctx.stats()))
+    return out
+
+
+def _check(ctx, label, n=4):
+    """n frames in a row with the cache on against one with it off."""
+    cached = _frames(ctx, n)
+    ctx.set_option("view_cache", 0)
+    plain, st0 = ctx.render().copy(), ctx.stats()
+    ctx.set_option("view_cache", 1)
+    for k, (img, st) in enumerate(cached):
+        assert np.array_equal(img.view(np.uint32), plain.view(np.uint32)), (label, k)
+        for key in KEYS:
+            assert st[key] == st0[key], (label, k, key, st[key], st0[key])
+    # the third and later frames of a run skipped transform, records and entry raster; the first two did not
+    # (c5_stats: the three stage times of a frame that reused are exactly 0)
+    assert cached[0][1]["ms_records"] > 0 and cached[1][1]["ms_records"] > 0, label
+    for k in range(2, n):
+        assert cached[k][1]["ms_records"] == 0 and cached[k][1]["ms_entries"] == 0 and cached[k][1]["ms_transform"] == 0, (label, k)
+    return plain
+
+
+def test_every_way_the_per_view_data_can_go_stale(gpu_ctx, product_solids):
+    xyz, cells, alpha, q = mg.workload("c2")  # the non-convex ball: re-entries, entries in the overflow pool
+    gpu_ctx.upload_grid(xyz, cells, alpha, q)
+    gpu_ctx.set_image(600, 450, mg.REFERENCE_BOUNDS)
+    va, vb = mg.view_rotations(0.1, 0.07), mg.view_rotations(0.4, -0.9)
+    gpu_ctx.set_view(va)
+    a = _check(gpu_ctx, "view a")
+    assert gpu_ctx.stats()["pool_entries"] > 0
+    gpu_ctx.set_view(vb)
+    b = _check(gpu_ctx, "view b")
+    assert not np.array_equal(a, b)
+    gpu_ctx.set_view(va)
+    a2 = _check(gpu_ctx, "view a again")
+    assert np.array_equal(a.view(np.uint32), a2.view(np.uint32))
+    gpu_ctx.set_alpha_limit(1.0)                      # the clamp is part of the records
+    c = _check(gpu_ctx, "alpha limit")
+    assert not np.array_equal(a, c)
+    gpu_ctx.set_alpha_limit(2.5)
+    gpu_ctx.update_scalars(alpha * 0.5, q)            # other scalars, same geometry
+    d = _check(gpu_ctx, "scalars")
+    assert not np.array_equal(a, d)
+    gpu_ctx.update_scalars(alpha, q)
+    gpu_ctx.set_option("integration", 1)              # the walk's direction: other entry lists
+    _check(gpu_ctx, "front to back")
+    gpu_ctx.set_option("integration", 0)
+    gpu_ctx.set_image(480, 360, mg.REFERENCE_BOUNDS)  # another image
+    _check(gpu_ctx, "image")
+    gpu_ctx.set_row_range(100, 120)                   # a block of its rows
+    _check(gpu_ctx, "row block")
+    gpu_ctx.set_row_range(0, -1)
+    gpu_ctx.set_image(600, 450, mg.REFERENCE_BOUNDS)
+    x2, c2 = mg.kuhn_box(6, jitter=0.1, seed=3)
+    a3, q3 = mg.scalars(len(c2), seed=4)
+    gpu_ctx.upload_grid(x2, c2, a3, q3)               # another grid
+    e = _check(gpu_ctx, "grid")
+    assert not np.array_equal(a, e)
+    # the donor sweep: the grid's view stays, a solid turns in front of it frame after frame
+    lobe, _ = product_solids
+    gpu_ctx.upload_grid(xyz, cells, alpha, q)
+    gpu_ctx.set_solid(0, lobe.reshape(-1, 12), float("nan"))
+    masks = []
+    for k in range(6):
+        gpu_ctx.set_solid_view(0, np.vstack([[1.0, k / 6.0 * PI, 1.0], va]))
+        img, st = gpu_ctx.render().copy(), gpu_ctx.stats()
+        gpu_ctx.set_option("view_cache", 0)
+        plain, st0 = gpu_ctx.render().copy(), gpu_ctx.stats()
+        gpu_ctx.set_option("view_cache", 1)
+        # (switching the option makes the per-view data stale: the next two frames build them again - so this loop only
+        # checks results; the run below checks that a real sweep reuses)
+        assert np.array_equal(img.view(np.uint32), plain.view(np.uint32)), k
+        assert all(st[key] == st0[key] for key in KEYS), k
+        masks.append(np.isnan(img[..., 0]))
+    assert not np.array_equal(masks[0], masks[3])
+    reused = 0
+    for k in range(8):
+        gpu_ctx.set_solid_view(0, np.vstack([[1.0, k / 8.0 * PI, 1.0], va]))
+        gpu_ctx.render()
+        st = gpu_ctx.stats()
+        reused += int(st["ms_records"] == 0 and st["ms_entries"] == 0)
+    assert reused == 6  # all but the first two frames of the sweep
+
+
+def test_a_starved_entry_pool_under_the_cache(gpu_ctx):
+    """An overflow pool that is too small: C5_RETRY, a larger pool, and the frames after it right - with the same view
+    throughout, so that the cache would reuse the INCOMPLETE lists if the retry did not make them stale."""
+    from course5_amd import capi
+    xyz, cells, alpha, q = mg.workload("c2")
+    gpu_ctx.upload_grid(xyz, cells, alpha, q)
+    gpu_ctx.set_image(600, 450, mg.REFERENCE_BOUNDS)
+    gpu_ctx.set_view(mg.view_rotations(0.1, 0.07))
+    gpu_ctx.set_option("view_cache", 0)
+    want = gpu_ctx.render().copy()
+    demand = gpu_ctx.stats()["pool_entries"]
+    assert demand > 100
+    gpu_ctx.set_option("view_cache", 1)
+    gpu_ctx.set_option("entry_pool", 64)
+    import torch
+    out = torch.zeros((450, 600, 2), dtype=torch.float32, device="cuda:0")
+    for _ in range(4):  # same view, frames in a row: the third would reuse what the first two built
+        gpu_ctx.render_device(out.data_ptr())
+    assert gpu_ctx.synchronize() == capi.C5_RETRY
+    for k in range(4):
+        img = gpu_ctx.render()
+        assert np.array_equal(img.view(np.uint32), want.view(np.uint32)), k
