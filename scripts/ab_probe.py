@@ -19,6 +19,7 @@ for p in paths:
     capi._lib = None
     capi.LIB_PATH = p
     ctx = capi.Context(0)
+    ctx.set_option("view_cache", 0)  # a benchmark of identical frames: each one does its whole per-view setup
     ctx.upload_grid(xyz, cells, alpha, q)
     ctx.set_image(res[0], res[1], mg.REFERENCE_BOUNDS)
     ctx.set_view(mg.view_rotations(**mg.BENCH_VIEW))

@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from course5_amd import capi, meshgen as mg
 ctx = capi.Context(0)
+ctx.set_option("view_cache", 0)  # a benchmark of identical frames: each one does its whole per-view setup
 xyz, c, a, q = mg.workload("c3")
 ctx.upload_grid(xyz, c, a, q)
 res = (2400, 1800) if len(sys.argv) < 2 else tuple(int(v) for v in sys.argv[1].split("x"))

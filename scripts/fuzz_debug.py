@@ -14,6 +14,7 @@ xyz, cells, alpha, q, rots, res, limit = fz.scene(seed)
 o = Oracle("port")
 ref = o.render(xyz, cells, alpha, q, rots, res[0], res[1], mg.REFERENCE_BOUNDS, alpha_limit=limit, threads=8)
 ctx = capi.Context(0)
+ctx.set_option("view_cache", 0)  # a benchmark of identical frames: each one does its whole per-view setup
 ctx.upload_grid(xyz, cells, alpha, q); ctx.set_image(res[0], res[1], mg.REFERENCE_BOUNDS); ctx.set_view(rots); ctx.set_alpha_limit(limit)
 if os.environ.get("C5_STEEP_RATIO"):
     ctx.set_option("steep_ratio", float(os.environ["C5_STEEP_RATIO"]))

@@ -13,6 +13,7 @@ dev = torch.device("cuda", 0)
 for name, res in (("c2", (1200, 900)), ("c3", (2400, 1800))):
     xyz, cells, alpha, q = mg.workload(name)
     ctx = capi.Context(0)
+    ctx.set_option("view_cache", 0)  # a benchmark of identical frames: each one does its whole per-view setup
     ctx.upload_grid(xyz, cells, alpha, q)
     ctx.set_image(*res, mg.REFERENCE_BOUNDS)
     ctx.set_view(mg.view_rotations(**mg.BENCH_VIEW))

@@ -20,6 +20,7 @@ outs = [torch.zeros((res[1], res[0], 2), dtype=torch.float32, device="cuda:0") f
 for spec in sys.argv[1:] or ["pipeline=0"]:
     opts = dict(kv.split("=") for kv in spec.split(",") if kv)
     ctx = capi.Context(0)
+    ctx.set_option("view_cache", 0)  # a benchmark of identical frames: each one does its whole per-view setup
     for k in ("pipeline",):
         if k in opts:
             ctx.set_option(k, float(opts.pop(k)))

@@ -12,6 +12,7 @@ xyz, c, a, q = mg.workload("c3")
 ctxs = []
 for _ in range(3):
     ctx = capi.Context(0)
+    ctx.set_option("view_cache", 0)  # a benchmark of identical frames: each one does its whole per-view setup
     ctx.upload_grid(xyz, c, a, q)
     ctx.set_image(res[0], res[1], mg.REFERENCE_BOUNDS)
     ctx.set_view(mg.view_rotations(0.1, 0.07))

@@ -12,6 +12,8 @@ res_x, res_y = 640, 480
 bad = 0
 for layout in ("full", "range", "tiles"):
     serial, piped = capi.Context(0), capi.Context(0)
+    serial.set_option("view_cache", 0)
+    piped.set_option("view_cache", 0)
     piped.set_option("pipeline", int(sys.argv[1]) if len(sys.argv) > 1 else 1)
     for c in (serial, piped):
         c.upload_grid(xyz, cells, alpha, q)

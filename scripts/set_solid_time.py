@@ -15,6 +15,7 @@ while off < len(raw):
     n = int(np.frombuffer(raw, dtype=np.int64, count=1, offset=off)[0])
     solids.append(np.frombuffer(raw, dtype=np.float64, count=12 * n, offset=off + 8).reshape(n, 12)); off += 8 + 96 * n
 ctx = capi.Context(0)
+ctx.set_option("view_cache", 0)  # a benchmark of identical frames: each one does its whole per-view setup
 for k, name in enumerate(("lobe", "sphere")):
     for rep in range(2):
         t = time.perf_counter(); ctx.set_solid(k, solids[k]); print(f"c5_set_solid {name} ({len(solids[k])} tets): {1e3 * (time.perf_counter() - t):.0f} ms")

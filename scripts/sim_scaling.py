@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 base = 6.0  # bench.py --row-base-cost
 ctx = capi.Context(0)
+ctx.set_option("view_cache", 0)  # a benchmark of identical frames: each one does its whole per-view setup
 xyz, c, a, q = mg.workload("c3")
 ctx.upload_grid(xyz, c, a, q)
 ctx.set_view(mg.view_rotations(0.1, 0.07))

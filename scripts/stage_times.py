@@ -6,6 +6,7 @@ import numpy as np
 from course5_amd import capi, meshgen as mg
 xyz, cells, alpha, q = mg.workload(sys.argv[1] if len(sys.argv) > 1 else "c3")
 ctx = capi.Context(0)
+ctx.set_option("view_cache", 0)  # a benchmark of identical frames: each one does its whole per-view setup
 ctx.upload_grid(xyz, cells, alpha, q)
 ctx.set_image(2400, 1800, mg.REFERENCE_BOUNDS)
 ctx.set_view(mg.view_rotations(**mg.BENCH_VIEW))

@@ -13,6 +13,7 @@ while off < len(raw):
     n = int(np.frombuffer(raw, dtype=np.int64, count=1, offset=off)[0])
     solids.append(np.frombuffer(raw, dtype=np.float64, count=12 * n, offset=off + 8).reshape(n, 12)); off += 8 + 96 * n
 ctx = capi.Context(0)
+ctx.set_option("view_cache", 0)  # a benchmark of identical frames: each one does its whole per-view setup
 xyz, c, a, q = mg.workload("c3")
 ctx.upload_grid(xyz, c, a, q)
 ctx.set_image(2400, 1800, mg.REFERENCE_BOUNDS)

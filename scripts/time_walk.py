@@ -3,6 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from course5_amd import capi, meshgen as mg
 ctx = capi.Context(0)
+ctx.set_option("view_cache", 0)  # a benchmark of identical frames: each one does its whole per-view setup
 xyz, c, a, q = mg.workload(sys.argv[1] if len(sys.argv) > 1 else "c3")
 ctx.upload_grid(xyz, c, a, q)
 res = (2400, 1800) if len(sys.argv) < 3 else tuple(int(v) for v in sys.argv[2].split("x"))
