@@ -72,7 +72,6 @@ def parse():
                         "frames = frame k of a sweep is rendered whole by rank k mod N, no exchange (config 5)")
     p.add_argument("--tile", type=int, default=-1, help="wavefront tile shape override (0: 64x1, 1: 16x4, 2: 8x8 in workgroups of four, 3: 8x8 one per workgroup)")
     p.add_argument("--lds-stage", type=int, default=-1, help="override: 2 = LDS-DMA staging (default), 1 = staged through vector registers, 0 = direct loads")
-    p.add_argument("--precision", type=int, default=-1, help="override of the \"precision\" option, if the library has it")
     p.add_argument("--pipeline", type=int, default=-1, help="override: overlap the next frame's setup with the walk (1) or not (0)")
     p.add_argument("--overlap-setup", type=int, default=-1, help="override: entry lists beside build_records (1) or serial (0)")
     p.add_argument("--own-stream", action="store_true", help="run on the context's own (high priority) stream")
@@ -83,7 +82,6 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-cpu-reference", action="store_true", help="skip the second CPU figure: the reference's own line.cpp / tetra.cpp object code, one thread (about half a minute)")
     p.add_argument("--no-host-image", action="store_true", help="skip the second figure: frames delivered to host memory")
-    p.add_argument("--no-mixed", action="store_true", help="skip the second figure with option \"precision\" 1")
     p.add_argument("--no-native", action="store_true", help="skip the figures of the C++ host (`course --bench`)")
     p.add_argument("--no-steady", action="store_true", help="skip the clock-steadying frames after the W warm-up steps (profiling passes)")
     p.add_argument("--cpu-sample-res", default="", help="image size of the CPU baseline (default: the benchmark's own)")
@@ -191,7 +189,7 @@ def product_solids():
     return soups
 
 
-def native_course_bench(xyz, cells, alpha, q, res_x, res_y, n_devices, frames, warmup, variants):
+def native_course_bench(xyz, cells, alpha, q, res_x, res_y, n_devices, frames, warmup, variants, rounds=5):
     """The C++ host (`course`, one process driving every GPU through one c5_context each) on the same grid,
     view and image: frames rendered and delivered to pinned host memory, no files.  Secondary figures; a
     failure here is recorded, never fatal."""
@@ -207,9 +205,9 @@ def native_course_bench(xyz, cells, alpha, q, res_x, res_y, n_devices, frames, w
             for name, extra in variants:
                 cmd = [exe, "-f", src, "-d", os.path.join(d, "frame.vti"), "--no_solids", "-x", str(res_x), "-y", str(res_y), "-X", str(mg.BENCH_VIEW["angle_around_x"]),
                        "-Y", str(mg.BENCH_VIEW["angle_around_y"]), "--bench", str(frames), "--bench_warmup", str(warmup),
-                       "--sweep", "Y", "--sweep_step", "0", "--devices", devs] + extra
+                       "--bench_rounds", str(rounds), "--sweep", "Y", "--sweep_step", "0", "--devices", devs] + extra
                 try:
-                    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+                    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                     line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"course_bench"')]
                     if r.returncode == 0 and line:
                         out[name] = json.loads(line[0])["course_bench"]
@@ -231,9 +229,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: start the N ranks as a CHILD job (one process per GPU under
+        # torch.distributed.run, exactly what the driver's documented command line does) BEFORE anything here has
+        # touched the GPU, hand its output through and leave with its exit code.  Never an exec.
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     import torch
     import torch.distributed as dist
@@ -254,6 +263,10 @@ def main():
         # host-side barriers for the phases in which the GPUs must be left alone (an RCCL barrier is a kernel that
         # spins on every GPU until the last rank arrives)
         cpu_group = dist.new_group(backend="gloo") if args.backend == "nccl" else None
+        # who is here: every rank's device ordinal, as the communicator itself sees the job (a SCALE record proves N ranks)
+        seen = [None] * world
+        dist.all_gather_object(seen, {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(),
+                                      "name": torch.cuda.get_device_name(dev), "pid": os.getpid()}, group=cpu_group)
 
     res_x, res_y = (int(v) for v in args.res.lower().split("x"))
     base_res = (res_x, res_y)
@@ -275,8 +288,6 @@ def main():
         ctx.set_option("tile", args.tile)
     if args.lds_stage >= 0:
         ctx.set_option("lds_stage", args.lds_stage)
-    if args.precision >= 0:
-        ctx.set_option("precision", args.precision)
     if args.overlap_setup >= 0:
         ctx.set_option("overlap_setup", args.overlap_setup)
     if not args.own_stream:
@@ -488,36 +499,6 @@ def main():
     if world == 1 and not args.no_host_image and hasattr(ctx, "render_host_async"):
         host_image = ctx.bench_host_frames(max(100, min(args.steps, 400)))
 
-    # Second figure: the same frames with option "precision" 1 (fp32 face planes about a cell-local lattice origin,
-    # fp64 accumulators; every parity test of tests/test_gpu_mixed.py holds the 1e-5 bar).  Never the headline:
-    # the reference computes in fp64 and so does `value`.
-    mixed = None
-    if world == 1 and args.precision < 0 and not args.no_mixed:
-        with torch.cuda.stream(stream):
-            ctx.set_option("precision", 1)
-            strip = torch.zeros((res_y, res_x, 2), dtype=torch.float32, device=dev)
-            for _ in range(60):
-                render(strip)
-            ctx.synchronize()
-            ctx.walk_kernel_ms(reset=True)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                render(strip)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            rc = ctx.synchronize()
-            wm, _ = ctx.walk_kernel_ms(reset=True)
-            st_m = ctx.stats()
-            ctx.set_option("precision", 0)
-            mixed = {"value": round(res_x * res_y * args.steps / dt / 1e6, 2), "unit": "Mrays/s",
-                     "ms_per_step": round(dt * 1e3 / args.steps, 4), "kernel_ms": round(wm, 4), "status": rc,
-                     "segments_per_frame": st_m["segments"],
-                     "what": "option \"precision\" 1: fp32 face planes about a cell-local origin on the pixel lattice "
-                             "(64-byte records), fp32 series for exp(-alpha dz) - 1, fp64 tau / I accumulators, cells with "
-                             "a face steep against the rays evaluated in fp64 (scalar loads); within the 1e-5 bar on every "
-                             "parity test, not bit-faithful"}
-
     # N > 1: BASELINE's other multi-GPU configurations, each beside the one-GPU time of the same work measured by rank 0
     # in this run.  Config 4: ONE 4800x3600 frame of the C3 grid split by rows.  Config 5: the 360-frame -D sweep with
     # the Roche lobe and the accretor sphere resident, whole frames dealt to the GPUs (frame k on rank k mod N, no
@@ -610,14 +591,18 @@ def main():
         torch.cuda.synchronize()
         host_barrier()
         if rank == 0:
-            k = max(20, min(args.steps, 200))
+            # The protocol of these legs does not follow --steps (BENCH_r03: 20 timed frames behind 5 warm ones gave 86
+            # frames/s where 120-frame runs give 130-150): >= 100 timed frames per round behind >= 20 warm ones (through
+            # the same path: writer thread, files), several rounds; the line carries the whole run, the fastest and the
+            # median round (ms_per_frame / _min / _median), and README / DESIGN quote exactly what this prints.
+            k = 100
             if world == 1:
                 # sweep_files: the reference's real workload end to end (utility/rotate_traces.py:16-21 renders 1 500
                 # frames of a -Y sweep to files): every timed frame rendered, copied to pinned memory, deflated and
                 # written as a zlib .vti by the writer thread while the next frames render
                 variants = [("one_gpu", []),
-                            ("sweep_files", ["--bench_files", "--sweep_step", "0.00555556", "--bench", str(max(20, min(args.steps, 120))),
-                                             "--bench_warmup", "5", "-j", str(usable_cpus())])]
+                            ("sweep_files", ["--bench_files", "--sweep_step", "0.00555556", "--bench", "100", "--bench_rounds", "3",
+                                             "--bench_warmup", "20", "-j", str(usable_cpus())])]
             else:
                 variants = [("rows_host", ["--split", "rows", "--exchange", "host"]),
                             ("rows_host_tiles", ["--split", "rows", "--exchange", "host", "--row_layout", "tiles"]),
@@ -625,7 +610,7 @@ def main():
                             ("rows_rccl_tiles", ["--split", "rows", "--exchange", "rccl", "--row_layout", "tiles"]),
                             ("rows_p2p", ["--split", "rows", "--exchange", "p2p"]),
                             ("frames", ["--split", "frames"])]
-            native = native_course_bench(xyz, cells, alpha, q, res_x, res_y, world, k, 20, variants)
+            native = native_course_bench(xyz, cells, alpha, q, res_x, res_y, world, k, 40, variants)
             if world > 1 and not args.no_configs:
                 c4x, c4y = (int(v) for v in args.config4_res.lower().split("x"))
                 native["config4"] = native_course_bench(xyz, cells, alpha, q, c4x, c4y, world, max(10, k // 2), 10,
@@ -702,8 +687,9 @@ def main():
             "metric": metric, "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak" if world == 1 else ("strong" if frame_parallel else args.scaling),
+            "scaling": "none" if world == 1 else ("strong" if frame_parallel else args.scaling),
             "vs_baseline": None, "dtype": "f64", "data": "synthetic", "retries": retries_total,
+            **({"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "ranks": seen} if world > 1 else {}),
             "steadying": {"batches_of_50_frames": len(steady), "walk_ms_per_batch": [round(v, 4) for v in steady]},
             "config": {"workload": f"{args.workload}: Kuhn box 55^3 = {cells.shape[0]} tets, {xyz.shape[0]} points, "
                                    f"jitter 0.1h, alpha~U[0,4) Q~U[0,1) seed 1234; {res_x}x{res_y}; view -X 0.1 -Y 0.07; "
@@ -741,8 +727,6 @@ def main():
             out["config5"] = config5
         if host_image is not None:
             out["value_host_image"] = host_image
-        if mixed is not None:
-            out["value_mixed_precision"] = mixed
         if native is not None:
             out["native_host"] = {"what": "the C++ host `course --bench` (one process, one c5_context per GPU) on the same grid, "
                                           "view and image; frames delivered to pinned host memory (sweep_files: written as zlib "

@@ -26,14 +26,12 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wex
 LIB_SOURCES = [
     ("exact_kernels.hip", ["-ffp-contract=off"]),   # must round like the reference's host build
     ("walk_kernels.hip", []),
-    ("walk_mixed.hip", []),
     ("c_api.hip", []),
     ("adjacency.cpp", ["-x", "c++", "-fopenmp"]),
 ]
 
 
-DEVICE_SOURCES = ("device_types.hpp", "kernels.hpp", "walk_common.hpp", "walk_mixed_common.hpp", "exact_kernels.hip",
-                  "walk_kernels.hip", "walk_mixed.hip")
+DEVICE_SOURCES = ("device_types.hpp", "kernels.hpp", "walk_common.hpp", "exact_kernels.hip", "walk_kernels.hip")
 
 
 def kernel_source_hash() -> str:

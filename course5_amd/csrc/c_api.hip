@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -98,17 +99,18 @@ bool same_image(const c5::ImageParams& a, const c5::ImageParams& b) {
 constexpr int kWalkEventPool = 512;
 constexpr size_t kStageChunk = size_t{4} << 20;  // pinned staging for pageable destinations, two of these
 constexpr int kFrameSlots = 2;
+constexpr int kStickyWords = 3;   // entries without a pool slot, rays over the step bound, rays that skipped an entry
+constexpr int kStatusWords = 3;   // a frame's own walk_overflow, entry_overflow, overlap_rays (FrameCounters, shard 0)
 constexpr size_t kCountersBytes = sizeof(c5::FrameCounters) * c5::kCounterShards;  // device_types.hpp
 
 // Everything one frame writes before its image: two slots, so that the per-view setup of frame
 // k + 1 (HBM-bound: transform, records, entry lists, solid mask) can run on the auxiliary stream
 // while walk_composite of frame k (VALU / address-path bound) runs on the main stream.
 struct FrameSlot {
-    DeviceBuffer vx, vy, vz, rec, opt, count, head, first, pool, mask, counters, row_cost;
+    DeviceBuffer vx, vy, vz, rec, count, head, first, pool, mask, counters, row_cost;
     DeviceBuffer sb;        // cost of the walk's rows of super-blocks in the last frame (WalkParams::sb_cost)
     long long sb_key = -1;  // the tiling they belong to (-1: not collected)
     int sb_n = 0;
-    DeviceBuffer geo, opt32, z0;  // "precision" 1: compact records (allocated on first use)
     // "view_cache": the per-view data in this slot (transformed vertices, records, entry lists) were built for ...
     uint64_t setup_epoch = 0;     // ... this state of the context (c5_context::setup_epoch; 0: nothing built)
     c5::RotationList setup_view{};
@@ -116,13 +118,9 @@ struct FrameSlot {
     int setup_order = 0;
     bool setup_kept = false;      // ... and the walk that used them left the entry heads in place
     bool setup_reused = false;    // the last frame enqueued into this slot skipped the per-view setup
+    const c5::FrameCounters* raster_counters = nullptr;  // device: counters of the frame whose raster built the slot's entry lists
     int64_t entry_capacity = 0;
     bool head_clean = false;  // the per-pixel entry heads are all zero (the walk kernels leave them so)
-    bool optics_valid = false;  // opt[] holds the optics of the current scalars for (optics_limit, optics_order)
-    double optics_limit = 0.0;
-    int optics_order = 0;
-    bool optics32_valid = false;  // the same for opt32[] ("precision" 1; its source term does not depend on the order)
-    double optics32_limit = 0.0;
     c5::FrameCounters* host_counters = nullptr;  // pinned
     hipEvent_t setup_done = nullptr, walk_done = nullptr;
     bool walk_recorded = false;
@@ -150,7 +148,6 @@ struct c5_context {
     int sb_order_n = 0;
     uint32_t* host_sb = nullptr;  // pinned: the last frame's per-row costs
     int entry_key = 1;      // "entry_key": 1 = entries keyed a slack behind their face (hanging-node interfaces), 0 = at the face (testing)
-    int optics_once = 1;    // "optics_once": the cells' optics are rebuilt only when scalars, limit or order changed
     int stage_slots = 0;    // "stage_slots": 0 = chosen per frame from rays_per_cell, or 14 / 21
     double rays_per_cell = 0.0;  // of the last finished frame (0: none yet)
     int solid_cache = 1;    // a solid unchanged since the frame before is not rastered again (enqueue_solids)
@@ -166,8 +163,11 @@ struct c5_context {
     FrameSlot slots[kFrameSlots];
     int64_t frame_index = 0;
     int last_slot = 0;
+    void* last_counters = nullptr;  // device: the counters the last enqueued frame adds to (the slot's, or a host-ring frame's own)
+    int row_cost_slot = 0;          // the slot whose row_cost[] holds the segments per row of the last frame that counted them
     int algorithm = 0;        // 0: walk, 1: bin_sort_resolve
-    bool grid_conforming = true;
+    bool grid_conforming = true;   // no face in more than two cells (c5_upload_grid)
+    bool overlap_seen = false;     // a frame's walk met interpenetrating components (finish_frame): bin_sort_resolve until the next upload
     DeviceBuffer offs64, scratch64, segs;  // bin_sort_resolve
     int pipeline = 0;  // measured at the end of round 1: 0.689 ms per C3 frame with it, 0.702 without
     c5::RotationList view{};
@@ -179,7 +179,7 @@ struct c5_context {
     c5::ImageParams im{};
     int cfg_tile_rows = 0, cfg_rank = 0, cfg_world = 1;
     int cfg_row_begin = 0, cfg_row_count = -1;  // -1: all rows
-    DeviceBuffer xtab, ytab, out, sticky;  // sticky: 2 x u32 failure words that persist across frames
+    DeviceBuffer xtab, ytab, out, sticky;  // sticky: kStickyWords x u32 failure words that persist across frames (kernels.hpp: WalkParams::sticky)
     unsigned* host_sticky = nullptr;       // pinned copy, refreshed at the end of every frame
     std::vector<double> host_ytab;
     int row_costs = 0;
@@ -193,8 +193,6 @@ struct c5_context {
     int lds_pad = 0;
     int band_rows = 0;
     int order = 0;
-    double steep_ratio = 64.0;   // "precision" 1: cells whose fp32 plane terms exceed this many cell extents are evaluated in fp64
-    int precision = 0;  // 0: fp64 walk, bit-faithful (default); 1: fp32 geometry + fp64 accumulators (walk_mixed.hip)
     int lds_stage = 2;
     int stage_timing = 1;
     int walk_timing = 1;
@@ -209,8 +207,11 @@ struct c5_context {
     // frames delivered to host memory (c5_render_host_async / _wait, c5_render)
     struct HostFrame {
         DeviceBuffer img;
+        // statistics of THIS frame (FrameCounters[kCounterShards]): frames in flight never share them, so the frame's own
+        // failure words can be read behind it whatever the frames after it are doing
+        DeviceBuffer counters;
         hipEvent_t rendered = nullptr, copied = nullptr;
-        unsigned* status = nullptr;  // pinned: the two sticky words as they stood after this frame
+        unsigned* status = nullptr;  // pinned: {rays over the step bound, entries without a pool slot} of THIS frame
     };
     hipStream_t copy_stream = nullptr;
     HostFrame hring[C5_HOST_RING];
@@ -426,7 +427,7 @@ int enqueue_solids(c5_context* ctx, FrameSlot& fs, int slot_id, hipStream_t s, c
 // bin_sort_resolve: the reference's algorithm (plane.cpp:184-192 + 144-172) on the GPU.  Needs the
 // segment total on the host between its two binning passes, so it synchronises.
 int enqueue_bin_sort(c5_context* ctx, FrameSlot& fs, const c5::GridView& g, int slot_id, float2* out_dev,
-                     hipStream_t s, hipStream_t main_s, bool timed) {
+                     hipStream_t s, hipStream_t main_s, bool timed, c5::FrameCounters* counters) {
     const c5::ImageParams& im = ctx->im;
     const int64_t n_px = static_cast<int64_t>(im.n_local_rows) * im.res_x;
     const int64_t padded = ((n_px + 1023) / 1024) * 1024;
@@ -435,7 +436,7 @@ int enqueue_bin_sort(c5_context* ctx, FrameSlot& fs, const c5::GridView& g, int 
     C5_HIP(ctx, ctx->offs64.ensure(static_cast<size_t>(padded + 1024) * sizeof(int64_t)));
     C5_HIP(ctx, ctx->scratch64.ensure(static_cast<size_t>(padded / 1024 + 1024) * sizeof(int64_t)));
     C5_HIP(ctx, hipMemsetAsync(fs.count.ptr, 0, static_cast<size_t>(padded + 1) * sizeof(int32_t), s));
-    unsigned* odd = &fs.counters.as<c5::FrameCounters>()->odd_pixels;
+    unsigned* odd = &counters->odd_pixels;
     c5::launch_bin_count(s, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im, fs.count.as<int32_t>(), odd);
     c5::launch_scan64(s, fs.count.as<int32_t>(), ctx->offs64.as<int64_t>(), n_px, ctx->scratch64.as<int64_t>());
     int64_t total = 0;
@@ -451,11 +452,11 @@ int enqueue_bin_sort(c5_context* ctx, FrameSlot& fs, const c5::GridView& g, int 
     if (rc) return rc;
     C5_HIP(ctx, mark(4, s));
     c5::launch_resolve(s, g, im, ctx->offs64.as<int64_t>(), ctx->segs.ptr, any_solid ? fs.mask.as<uint32_t>() : nullptr,
-                       table, ctx->alpha_limit, out_dev, fs.counters.as<c5::FrameCounters>());
+                       table, ctx->alpha_limit, out_dev, counters);
     C5_HIP(ctx, mark(5, s));
     C5_HIP(ctx, hipGetLastError());
-    C5_HIP(ctx, hipMemcpyAsync(fs.host_counters, fs.counters.ptr, kCountersBytes, hipMemcpyDeviceToHost, s));
-    C5_HIP(ctx, hipMemcpyAsync(ctx->host_sticky, ctx->sticky.ptr, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    C5_HIP(ctx, hipMemcpyAsync(fs.host_counters, counters, kCountersBytes, hipMemcpyDeviceToHost, s));
+    C5_HIP(ctx, hipMemcpyAsync(ctx->host_sticky, ctx->sticky.ptr, kStickyWords * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     C5_HIP(ctx, hipStreamSynchronize(s));
     ctx->counters_on_host = true;
     fs.host_counters->segments = static_cast<unsigned long long>(total);
@@ -466,6 +467,7 @@ int enqueue_bin_sort(c5_context* ctx, FrameSlot& fs, const c5::GridView& g, int 
         fs.walk_recorded = true;
     }
     ctx->last_slot = slot_id;
+    ctx->last_counters = counters;
     ctx->frame_index += 1;
     ctx->frame_pending = true;
     ctx->frame_timed = timed;
@@ -475,7 +477,9 @@ int enqueue_bin_sort(c5_context* ctx, FrameSlot& fs, const c5::GridView& g, int 
 // Enqueue one frame; the image goes to out_dev.  The per-view setup runs on the auxiliary stream
 // into frame slot (frame_index & 1), the walk on the main stream once that setup is done, so the
 // setup of the next frame overlaps this frame's walk.
-int enqueue_frame(c5_context* ctx, float2* out_dev) {
+// own_counters: the frame's statistics go to these FrameCounters[kCounterShards] instead of the slot's (frames delivered to
+// host memory: each frame of the ring keeps its own, c5_render_host_async).
+int enqueue_frame(c5_context* ctx, float2* out_dev, c5::FrameCounters* own_counters = nullptr) {
     if (ctx->n_cells <= 0 && [&] {
             for (const Solid& s : ctx->solids)
                 if (s.n_tets > 0) return false;
@@ -495,6 +499,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     const int64_t padded = ((n_px + 1023) / 1024) * 1024;
     const bool timed = ctx->stage_timing != 0;
     auto mark = [&](int k, hipStream_t st) -> hipError_t { return timed ? hipEventRecord(fs.ev[k], st) : hipSuccess; };
+    c5::FrameCounters* const counters = own_counters ? own_counters : fs.counters.as<c5::FrameCounters>();
 
     // the slot's buffers are free once the walk that last read them has finished
     if (ctx->pipeline && fs.walk_recorded) C5_HIP(ctx, hipStreamWaitEvent(s, fs.walk_done, 0));
@@ -517,7 +522,6 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     g.q = ctx->q.as<double>();
     g.bface = ctx->bface.as<uint32_t>();
     g.xrec = fs.rec.as<c5::ExitRecord>();
-    g.rec = fs.rec.as<c5::CellRecord>();
     // y band of the rows this context renders (one pixel of slack on both sides)
     if (im.n_local_rows > 0) {
         const int first = c5::global_row_of(im, 0), last = c5::global_row_of(im, im.n_local_rows - 1);
@@ -552,15 +556,14 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     }
     fs.sb_key = sb_key;
     fs.sb_n = n_sb;
-    const bool bin_sort = ctx->algorithm == 1 || !ctx->grid_conforming;
+    const bool bin_sort = ctx->algorithm == 1 || !ctx->grid_conforming || ctx->overlap_seen;
     // "view_cache" (the persistent device grid of a -D sweep: only the donor turns, main.cpp:112-116): transformed
     // vertices, records and entry lists depend on the grid, the image, the view, the alpha limit and the order - a frame
     // that has all of them in common with the frame before reuses them.  The walk normally hands the entry heads back
     // cleared, so it takes TWO frames with the same view in a row before there is something to reuse: the second one
     // builds everything once more and tells its walk to leave the heads alone; the third and later ones skip the
     // per-view setup.  A sweep whose view changes every frame never pays for any of this.
-    const bool cacheable = ctx->view_cache && !ctx->pipeline && !bin_sort && !ctx->fuse_setup && !ctx->overlap_setup &&
-                           !(ctx->precision == 1 && c5::mixed_precision_fits(ctx->n_cells, im)) && g.n_cells > 0;
+    const bool cacheable = ctx->view_cache && !ctx->pipeline && !bin_sort && !ctx->fuse_setup && !ctx->overlap_setup && g.n_cells > 0;
     const bool same_view = cacheable && fs.setup_epoch == ctx->setup_epoch && same_rotations(fs.setup_view, ctx->view) &&
                            fs.setup_limit == ctx->alpha_limit && fs.setup_order == ctx->order;
     const bool reuse = same_view && fs.setup_kept;
@@ -570,13 +573,14 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     fs.setup_limit = ctx->alpha_limit;
     fs.setup_order = ctx->order;
     fs.setup_kept = same_view;  // (this frame's walk leaves the heads in place)
-    if (reuse)
-        c5::launch_clear_walk_counters(s, fs.counters.as<c5::FrameCounters>(), sb, n_sb);
-    else
-        c5::launch_transform_soa(s, g.px, g.py, g.pz, g.vx, g.vy, g.vz, g.n_pts, ctx->view,
-                                 fs.counters.as<c5::FrameCounters>(), sb, n_sb);
+    if (reuse) {
+        c5::launch_clear_walk_counters(s, counters, sb, n_sb, fs.raster_counters);
+    } else {
+        c5::launch_transform_soa(s, g.px, g.py, g.pz, g.vx, g.vy, g.vz, g.n_pts, ctx->view, counters, sb, n_sb);
+        fs.raster_counters = counters;  // (this frame's raster adds its pool demand / overflow here)
+    }
     C5_HIP(ctx, mark(1, s));
-    if (bin_sort) return enqueue_bin_sort(ctx, fs, g, slot_id, out_dev, s, main_s, timed);
+    if (bin_sort) return enqueue_bin_sort(ctx, fs, g, slot_id, out_dev, s, main_s, timed, counters);
     // (a1, a10, a13 constants) per-cell records on the setup stream; the boundary entry lists and the
     // solid mask need only the transformed vertices, so they run beside it on a side stream (they are
     // small, latency-bound launches).  With stage timing on, everything stays in one stream so that
@@ -587,43 +591,17 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
         C5_HIP(ctx, hipEventRecord(ctx->fork_ev, s));
         C5_HIP(ctx, hipStreamWaitEvent(e, ctx->fork_ev, 0));
     }
-    // "precision" 1 needs the LDS-staged walk's preconditions and its own limits; otherwise the fp64 walk serves
-    const bool mixed = ctx->precision == 1 && c5::mixed_precision_fits(ctx->n_cells, im);
-    if (mixed) {
-        const size_t nc = static_cast<size_t>(ctx->n_cells);
-        // geometry and optics in ONE allocation, the optics behind the geometry: the walk's staging loads (LDS-DMA)
-        // reach both with one 32-bit offset from the geometry
-        const size_t opt32_at = (nc * sizeof(c5::GeoRecord) + 64 + 255) & ~static_cast<size_t>(255);
-        if (fs.geo.bytes < opt32_at + nc * sizeof(c5::OptRecord) + 256) {
-            // records of cells outside a context's row band are never rebuilt: whatever they hold must be a valid
-            // record (zeros: neighbour ids inside the grid)
-            C5_HIP(ctx, fs.geo.ensure(opt32_at + nc * sizeof(c5::OptRecord) + 256));
-            C5_HIP(ctx, fs.z0.ensure(nc * sizeof(float) + 4));
-            C5_HIP(ctx, hipMemsetAsync(fs.geo.ptr, 0, fs.geo.bytes, s));
-            C5_HIP(ctx, hipMemsetAsync(fs.z0.ptr, 0, fs.z0.bytes, s));
-            fs.optics32_valid = false;
-        }
-        g.geo = fs.geo.as<c5::GeoRecord>();
-        g.opt32 = reinterpret_cast<c5::OptRecord*>(static_cast<char*>(fs.geo.ptr) + opt32_at);
-        g.z0 = fs.z0.as<float>();
-        const bool optics_stale = !ctx->optics_once || !fs.optics32_valid || fs.optics32_limit != ctx->alpha_limit;
-        c5::launch_build_records_mixed(s, g, im, ctx->xtab.as<double>(), ctx->ytab.as<double>(), ctx->alpha_limit, ctx->order, ctx->steep_ratio,
-                                       optics_stale);
-        fs.optics32_valid = true;
-        fs.optics32_limit = ctx->alpha_limit;
-    } else if (!(ctx->fuse_setup && !side && g.n_cells > 0) && !reuse) {
+    if (!(ctx->fuse_setup && !side && g.n_cells > 0) && !reuse) {
         // (a cell's optics ride in its record since round 3 — one line per cell and step — and are rewritten with it)
         c5::launch_build_records(s, g, ctx->alpha_limit, ctx->order);
     }
-    const bool fused = !mixed && ctx->fuse_setup && !side && g.n_cells > 0;
+    const bool fused = ctx->fuse_setup && !side && g.n_cells > 0;
     if (!fused) C5_HIP(ctx, mark(2, s));
     // boundary entries: one raster pass (per-pixel count + first entry + overflow chain)
     // the frame's uniform entry-key slack (walk_common.hpp: entry_key_slack): a fraction of the GRID's size — not of
     // the image domain's: a slack larger than a whole ray would let a pixel that two boundary faces both claim (its
     // centre exactly on their common edge) walk the same cells twice — plus the rounding of an absolute depth
-    const double key_slack = !ctx->entry_key ? -1.0
-                             : (mixed ? c5::kEntryKeySlackMixed * ctx->grid_diagonal + 0x1p-22 * ctx->coord_max
-                                      : c5::kEntryKeySlack * ctx->grid_diagonal + 0x1p-40 * ctx->coord_max);
+    const double key_slack = !ctx->entry_key ? -1.0 : c5::kEntryKeySlack * ctx->grid_diagonal + 0x1p-40 * ctx->coord_max;
     if (!fs.head_clean && !reuse) C5_HIP(ctx, hipMemsetAsync(fs.head.ptr, 0, static_cast<size_t>(padded) * sizeof(c5::EntryHead), e));
     fs.head_clean = false;
     if (fused) {
@@ -631,13 +609,12 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
         // time of both and ms_entries is zero)
         c5::launch_setup_fused(s, g, ctx->alpha_limit, ctx->order, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im,
                                fs.head.as<c5::EntryHead>(), fs.first.as<c5::Entry>(), fs.pool.as<c5::Entry>(), fs.entry_capacity,
-                               fs.counters.as<c5::FrameCounters>(), ctx->sticky.as<unsigned>(), ctx->order != 0, key_slack);
+                               counters, ctx->sticky.as<unsigned>(), ctx->order != 0, key_slack);
         C5_HIP(ctx, mark(2, s));
     } else if (g.n_cells > 0 && !reuse) {
         c5::launch_entry_lists(e, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im, fs.head.as<c5::EntryHead>(),
-                               fs.first.as<c5::Entry>(), fs.pool.as<c5::Entry>(), fs.entry_capacity,
-                               fs.counters.as<c5::FrameCounters>(), ctx->sticky.as<unsigned>(), ctx->order != 0,
-                               key_slack);
+                               fs.first.as<c5::Entry>(), fs.pool.as<c5::Entry>(), fs.entry_capacity, counters,
+                               ctx->sticky.as<unsigned>(), ctx->order != 0, key_slack);
     }
     C5_HIP(ctx, mark(3, e));
     // (a9) solids
@@ -654,11 +631,6 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     // (a11-a14) walk on the main stream, after this slot's setup
     c5::WalkParams wp{};
     wp.xrec = g.xrec;
-    wp.rec = g.rec;
-    wp.geo = g.geo;
-    wp.opt32 = g.opt32;
-    wp.z0 = g.z0;
-    wp.precision = mixed ? 1 : 0;
     wp.entry_head = fs.head.as<c5::EntryHead>();
     wp.entry_first = fs.first.as<c5::Entry>();
     wp.entry_pool = fs.pool.as<c5::Entry>();
@@ -679,7 +651,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
     wp.order = ctx->order;
     // walk_composite_lds addresses the records by 32-bit byte offsets: n_cells * 128 must fit
     wp.lds_stage = (ctx->lds_stage && ctx->n_cells < (int64_t{1} << 25)) ? ctx->lds_stage : 0;
-    wp.counters = fs.counters.as<c5::FrameCounters>();
+    wp.counters = counters;
     {   // every exp argument of this grid within (-1/8, 0]?  alpha_c <= min(limit, largest alpha), chord <= longest edge
         double a_max = std::fmin(ctx->alpha_top, ctx->alpha_limit);
         if (!(a_max >= 0.0)) a_max = ctx->alpha_top;  // (a NaN limit clamps nothing: line.cpp:216-218)
@@ -698,6 +670,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
         wp.row_cost = fs.row_cost.as<uint32_t>();
         C5_HIP(ctx, hipMemsetAsync(fs.row_cost.ptr, 0, static_cast<size_t>(im.n_local_rows) * sizeof(uint32_t), s));
         ctx->row_costs_collected = true;
+        ctx->row_cost_slot = slot_id;  // ("pipeline" alternates the slots: the costs stay in the slot of the frame that counted them)
     }
     if (ctx->pipeline) {
         C5_HIP(ctx, hipEventRecord(fs.setup_done, s));
@@ -719,10 +692,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
         ev_slot = ctx->walk_used++;
         C5_HIP(ctx, hipEventRecord(ctx->walk_a[ev_slot], main_s));
     }
-    if (mixed)
-        c5::launch_walk_mixed(main_s, wp, ctx->tile_shape);
-    else
-        c5::launch_walk(main_s, wp, ctx->tile_shape);
+    c5::launch_walk(main_s, wp, ctx->tile_shape);
     fs.head_clean = !wp.keep_entries;  // stream order: every pixel's head is zero again once the walk has run
     if (ev_slot >= 0) C5_HIP(ctx, hipEventRecord(ctx->walk_b[ev_slot], main_s));
     C5_HIP(ctx, mark(5, main_s));
@@ -735,6 +705,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev) {
         fs.walk_recorded = true;
     }
     ctx->last_slot = slot_id;
+    ctx->last_counters = counters;
     ctx->frame_index += 1;
     ctx->frame_pending = true;
     ctx->frame_timed = timed;
@@ -747,8 +718,8 @@ int finish_frame(c5_context* ctx);
 int wait_and_collect(c5_context* ctx) {
     if (ctx->frame_pending && !ctx->counters_on_host) {
         FrameSlot& fs = ctx->slots[ctx->last_slot];
-        C5_HIP(ctx, hipMemcpyAsync(fs.host_counters, fs.counters.ptr, kCountersBytes, hipMemcpyDeviceToHost, ctx->stream));
-        C5_HIP(ctx, hipMemcpyAsync(ctx->host_sticky, ctx->sticky.ptr, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        C5_HIP(ctx, hipMemcpyAsync(fs.host_counters, ctx->last_counters ? ctx->last_counters : fs.counters.ptr, kCountersBytes, hipMemcpyDeviceToHost, ctx->stream));
+        C5_HIP(ctx, hipMemcpyAsync(ctx->host_sticky, ctx->sticky.ptr, kStickyWords * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
         if (fs.sb_key >= 0 && fs.sb.ptr && ctx->host_sb)
             C5_HIP(ctx, hipMemcpyAsync(ctx->host_sb, fs.sb.ptr, c5::kMaxSbRows * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         ctx->counters_on_host = true;
@@ -832,18 +803,22 @@ int finish_frame(c5_context* ctx) {
     // failures of ANY frame since the last look (several frames may have been in flight)
     const int64_t refused = static_cast<int64_t>(ctx->host_sticky[0]);  // entries that found no slot, all those frames
     const unsigned lost_rays = ctx->host_sticky[1];
+    const unsigned overlap_rays = ctx->host_sticky[2];
     const bool too_small = refused > 0;
-    if (too_small || lost_rays) {
+    if (too_small || lost_rays || overlap_rays) {
         int rc = drain(ctx);
         if (rc) return rc;
         // Frames delivered to host memory that are still outstanding were all enqueued before this moment, i.e.
         // rendered with the buffers that were too small: their waits must say so whatever their status snapshots
         // read (a snapshot is copied on the copy stream and may run after the words are cleared here) — also when
         // it is c5_get_stats / c5_get_row_costs / c5_synchronize, not c5_render_host_wait, that notices first.
-        if (too_small) ctx->hr_retry_left = ctx->hr_count;
+        if (too_small || overlap_rays) ctx->hr_retry_left = ctx->hr_count;
         if (ctx->copy_stream && ctx->hr_count) C5_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
-        C5_HIP(ctx, hipMemset(ctx->sticky.ptr, 0, 2 * sizeof(unsigned)));
-        ctx->host_sticky[0] = ctx->host_sticky[1] = 0;
+        // cleared IN the stream the kernels that add to it run on, and waited for: nothing rests on how the NULL stream
+        // is ordered against this context's non-blocking streams
+        C5_HIP(ctx, hipMemsetAsync(ctx->sticky.ptr, 0, kStickyWords * sizeof(unsigned), ctx->stream));
+        C5_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < kStickyWords; ++k) ctx->host_sticky[k] = 0;
     }
     // Keep the pool at twice the demand just seen (plus a margin): the demand is a smooth function of the
     // view, so in a sweep the pool grows ahead of it, between frames, without a frame ever being lost.
@@ -870,6 +845,16 @@ int finish_frame(c5_context* ctx) {
     }
     if (lost_rays)
         return fail(ctx, C5_ERR_WALK, "%u rays exceeded the walk step bound (malformed grid?)", lost_rays);
+    if (overlap_rays) {
+        // Cells of two components that share no face interpenetrate (walk_common.hpp: next_entry): the reference bins and
+        // sorts such a soup (plane.cpp:184-192, line.cpp:138), a walk cannot render it.  From here on this grid goes
+        // through bin_sort_resolve, like a grid with a face in more than two cells (c5_upload_grid).
+        ctx->overlap_seen = true;
+        ++ctx->setup_epoch;
+        return fail(ctx, C5_RETRY,
+                    "%u rays met a boundary entry inside a stretch of cells they had walked: components of the grid interpenetrate; "
+                    "every frame since the last c5_synchronize is wrong, render again (bin_sort_resolve from now on)", overlap_rays);
+    }
     return C5_OK;
 }
 
@@ -930,9 +915,9 @@ int c5_create(int device_ordinal, c5_context** out_ctx) {
     for (c5_context::HostFrame& h : ctx->hring) {
         if ((e = hipEventCreateWithFlags(&h.rendered, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
         if ((e = hipEventCreateWithFlags(&h.copied, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
-        if ((e = hipHostMalloc(reinterpret_cast<void**>(&h.status), 2 * sizeof(unsigned), hipHostMallocDefault)) != hipSuccess)
+        if ((e = hipHostMalloc(reinterpret_cast<void**>(&h.status), 4 * sizeof(unsigned), hipHostMallocDefault)) != hipSuccess)
             return bail(e, "hipHostMalloc");
-        h.status[0] = h.status[1] = 0;
+        h.status[0] = h.status[1] = h.status[2] = h.status[3] = 0;
     }
     for (int k = 0; k < 2; ++k)
         if ((e = hipEventCreateWithFlags(&ctx->stage_ev[k], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -956,11 +941,13 @@ int c5_create(int device_ordinal, c5_context** out_ctx) {
         if ((e = hipEventCreate(&ctx->walk_a[k])) != hipSuccess) return bail(e, "hipEventCreate");
         if ((e = hipEventCreate(&ctx->walk_b[k])) != hipSuccess) return bail(e, "hipEventCreate");
     }
-    if ((e = ctx->sticky.ensure(2 * sizeof(unsigned))) != hipSuccess) return bail(e, "hipMalloc");
-    if ((e = hipMemset(ctx->sticky.ptr, 0, 2 * sizeof(unsigned))) != hipSuccess) return bail(e, "hipMemset");
-    if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->host_sticky), 2 * sizeof(unsigned), hipHostMallocDefault)) != hipSuccess)
+    // (a line of its own; cleared in the context's own stream and waited for — see finish_frame)
+    if ((e = ctx->sticky.ensure(256)) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMemsetAsync(ctx->sticky.ptr, 0, 256, ctx->own_stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
+    if ((e = hipStreamSynchronize(ctx->own_stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->host_sticky), 4 * sizeof(unsigned), hipHostMallocDefault)) != hipSuccess)
         return bail(e, "hipHostMalloc");
-    ctx->host_sticky[0] = ctx->host_sticky[1] = 0;
+    for (int k = 0; k < 4; ++k) ctx->host_sticky[k] = 0;
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->host_sb), c5::kMaxSbRows * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
         ctx->host_sb = nullptr;  // (the walk then starts its rows in image order)
     else
@@ -983,8 +970,8 @@ void c5_destroy(c5_context* ctx) {
     if (ctx->host_sb) (void)hipHostFree(ctx->host_sb);
     for (DeviceBuffer* b : bufs) b->release();
     for (FrameSlot& fs : ctx->slots) {
-        DeviceBuffer* sb[] = {&fs.vx, &fs.vy, &fs.vz, &fs.rec, &fs.opt, &fs.count, &fs.head, &fs.first, &fs.pool,
-                              &fs.mask, &fs.counters, &fs.row_cost, &fs.geo, &fs.opt32, &fs.z0, &fs.sb};
+        DeviceBuffer* sb[] = {&fs.vx, &fs.vy, &fs.vz, &fs.rec, &fs.count, &fs.head, &fs.first, &fs.pool,
+                              &fs.mask, &fs.counters, &fs.row_cost, &fs.sb};
         for (DeviceBuffer* b : sb) b->release();
         if (fs.host_counters) (void)hipHostFree(fs.host_counters);
         for (auto& ev : fs.ev)
@@ -1005,6 +992,7 @@ void c5_destroy(c5_context* ctx) {
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     for (c5_context::HostFrame& h : ctx->hring) {
         h.img.release();
+        h.counters.release();
         if (h.rendered) (void)hipEventDestroy(h.rendered);
         if (h.copied) (void)hipEventDestroy(h.copied);
         if (h.status) (void)hipHostFree(h.status);
@@ -1093,15 +1081,11 @@ int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int3
         C5_HIP(ctx, fs.vx.ensure(pb ? pb : 8));
         C5_HIP(ctx, fs.vy.ensure(pb ? pb : 8));
         C5_HIP(ctx, fs.vz.ensure(pb ? pb : 8));
-        // one 128-byte record per cell and view (ExitRecord; "precision" 1 keeps a steep cell's SteepPlanes there)
+        // one 128-byte record per cell and view (ExitRecord)
         C5_HIP(ctx, fs.rec.ensure(cb * sizeof(c5::ExitRecord) + 256));
         // records of cells outside a context's row band are never rebuilt; keep whatever they hold a
         // valid record (neighbour ids inside the grid) from the start
         C5_HIP(ctx, hipMemset(fs.rec.ptr, 0, fs.rec.bytes));
-        fs.optics_valid = fs.optics32_valid = false;
-        fs.geo.release();  // "precision" 1 records of the old grid: rebuilt (and zeroed) on first use
-        fs.opt32.release();
-        fs.z0.release();
     }
     C5_HIP(ctx, ctx->cell_vert.ensure(cb * 16 + 16));
     C5_HIP(ctx, ctx->cell_adj.ensure(cb * 16 + 16));
@@ -1153,6 +1137,7 @@ int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int3
     ctx->n_cells = n_cells;
     ctx->n_bfaces = static_cast<int64_t>(bfaces.size());
     ctx->grid_conforming = conforming;
+    ctx->overlap_seen = false;
     return C5_OK;
 }
 
@@ -1168,7 +1153,6 @@ int c5_update_scalars(c5_context* ctx, const double* alpha, const double* q, int
         C5_HIP(ctx, hipMemcpy(ctx->alpha.ptr, alpha, static_cast<size_t>(n_cells) * 8, hipMemcpyHostToDevice));
         C5_HIP(ctx, hipMemcpy(ctx->q.ptr, q, static_cast<size_t>(n_cells) * 8, hipMemcpyHostToDevice));
     }
-    for (FrameSlot& fs : ctx->slots) fs.optics_valid = fs.optics32_valid = false;
     ctx->alpha_top = 0.0;
     for (int64_t i = 0; i < n_cells; ++i)
         if (alpha[i] > ctx->alpha_top) ctx->alpha_top = alpha[i];
@@ -1357,7 +1341,7 @@ int c5_get_row_costs(c5_context* ctx, uint32_t* costs, int n_rows) {
     int rc = c5_synchronize(ctx);
     if (rc) return rc;
     if (n_rows > 0)
-        C5_HIP(ctx, hipMemcpy(costs, ctx->slots[ctx->last_slot].row_cost.ptr, static_cast<size_t>(n_rows) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        C5_HIP(ctx, hipMemcpy(costs, ctx->slots[ctx->row_cost_slot].row_cost.ptr, static_cast<size_t>(n_rows) * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return C5_OK;
 }
 
@@ -1411,8 +1395,7 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
         ctx->cost_order = static_cast<int>(value) != 0;
     } else if (n == "entry_key") {
         ctx->entry_key = static_cast<int>(value) != 0;
-    } else if (n == "optics_once") {
-        ctx->optics_once = static_cast<int>(value) != 0;
+        ctx->overlap_seen = false;  // (with the testing value 0 an abutting entry can look like a skipped one: judge anew)
     } else if (n == "stage_slots") {
         if (value != 0 && value != 14 && value != 21) return fail(ctx, C5_ERR_INVALID, "stage_slots must be 0 (per frame), 14 or 21");
         ctx->stage_slots = static_cast<int>(value);
@@ -1431,12 +1414,6 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
         ctx->lds_stage = static_cast<int>(value) < 0 ? 0 : (static_cast<int>(value) > 2 ? 2 : static_cast<int>(value));
     } else if (n == "integration") {
         ctx->order = static_cast<int>(value) != 0;
-    } else if (n == "steep_ratio") {
-        if (!(value >= 0.0)) return fail(ctx, C5_ERR_INVALID, "steep_ratio must be >= 0 (0: never fall back to fp64)");
-        ctx->steep_ratio = value;
-    } else if (n == "precision") {
-        if (value != 0 && value != 1) return fail(ctx, C5_ERR_INVALID, "precision must be 0 (fp64) or 1 (mixed)");
-        ctx->precision = static_cast<int>(value);
     } else if (n == "entry_pool") {  // testing: (re)size the overflow pool of the entry lists, in records
         if (value < 1 || value > 16777214) return fail(ctx, C5_ERR_INVALID, "entry_pool out of range");
         int rc = drain(ctx);
@@ -1573,15 +1550,22 @@ int render_host_async(c5_context* ctx, float* out_host, bool into_full_frame) {
     c5_context::HostFrame& h = ctx->hring[ctx->hr_next];
     const size_t bytes = static_cast<size_t>(ctx->im.n_local_rows) * ctx->im.res_x * 2 * sizeof(float);
     C5_HIP(ctx, h.img.ensure(((bytes + 8191) / 8192) * 8192));
+    C5_HIP(ctx, h.counters.ensure(kCountersBytes));
     // (the slot's previous copy is complete: its c5_render_host_wait has returned)
-    rc = enqueue_frame(ctx, h.img.as<float2>());
+    rc = enqueue_frame(ctx, h.img.as<float2>(), h.counters.as<c5::FrameCounters>());
     if (rc) return rc;
     C5_HIP(ctx, hipEventRecord(h.rendered, ctx->stream));
     C5_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, h.rendered, 0));
     rc = enqueue_strip_copy(ctx, h.img.ptr, out_host, into_full_frame);
     if (rc) return rc;
-    // the failure words as they stand once this frame is through: the wait can tell without touching the render stream
-    C5_HIP(ctx, hipMemcpyAsync(h.status, ctx->sticky.ptr, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->copy_stream));
+    // THIS frame's failure words (walk_overflow, entry_overflow: adjacent in shard 0 of its own counters, cleared by its
+    // own first kernel): the wait can tell without touching the render stream, and no frame enqueued later adds to them.
+    // (Rounds 2-3 copied the context's cumulative sticky words here: a snapshot that depended on how a NULL-stream
+    // hipMemset of c5_create was ordered against this copy stream, and that a later frame's raster could add to.)
+    static_assert(offsetof(c5::FrameCounters, entry_overflow) == offsetof(c5::FrameCounters, walk_overflow) + sizeof(unsigned) &&
+                  offsetof(c5::FrameCounters, overlap_rays) == offsetof(c5::FrameCounters, walk_overflow) + 2 * sizeof(unsigned), "status = adjacent words");
+    C5_HIP(ctx, hipMemcpyAsync(h.status, reinterpret_cast<const char*>(h.counters.ptr) + offsetof(c5::FrameCounters, walk_overflow),
+                               kStatusWords * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->copy_stream));
     C5_HIP(ctx, hipEventRecord(h.copied, ctx->copy_stream));
     ctx->hr_next = (ctx->hr_next + 1) % C5_HOST_RING;
     ctx->hr_count += 1;
@@ -1605,11 +1589,18 @@ int c5_render_host_wait(c5_context* ctx) {
         ctx->hr_retry_left -= 1;
         return fail(ctx, C5_RETRY, "frame was enqueued before an internal buffer was grown: render it again");
     }
-    if (h.status[0] == 0 && h.status[1] == 0) return C5_OK;
-    // a failure somewhere up to this frame: settle it (waits for the render stream, grows what was too small)
+    if (h.status[0] == 0 && h.status[1] == 0 && h.status[2] == 0) return C5_OK;
+    // this frame failed: settle it (waits for the render stream, grows what was too small); every frame enqueued behind
+    // it used the same buffers
+    const unsigned lost = h.status[0], refused = h.status[1], overlapping = h.status[2];
     ctx->hr_retry_left = ctx->hr_count;
     rc = wait_and_collect(ctx);
-    if (rc == C5_OK) rc = fail(ctx, C5_RETRY, "an earlier frame overflowed an internal buffer: render again");
+    if (rc == C5_OK)
+        rc = fail(ctx, C5_RETRY, "frame incomplete (%u boundary entries without a pool slot, %u rays over the step bound, %u rays through "
+                  "interpenetrating cells by its own counters; the context's cumulative words read %u / %u / %u when the stream was waited "
+                  "for; pool now %lld records): render again",
+                  refused, lost, overlapping, ctx->host_sticky[0], ctx->host_sticky[1], ctx->host_sticky[2],
+                  static_cast<long long>(ctx->slots[0].entry_capacity));
     return rc;
 }
 

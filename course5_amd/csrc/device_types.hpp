@@ -78,28 +78,6 @@ struct alignas(16) ExitRecord {
 };
 static_assert(sizeof(ExitRecord) == 128, "ExitRecord must be one 128-byte line");
 
-// --- "precision" 1: the compact records of walk_composite_mixed --------------------------------------------
-// 64 bytes of geometry per cell, in single precision about a cell-local origin ON THE PIXEL LATTICE:
-//   z(col, row) - z0 = plane[k][0] + plane[k][1] * (col - col0) + plane[k][2] * (row - row0)
-// with (col0, row0) the pixel nearest the cell's vertex 0 and z0 a depth of the cell (kept apart, in z0[],
-// for the rare moment a ray leaves the grid and its absolute depth is wanted).  col - col0 is a small exact
-// integer, plane[k][0] is of the size of the cell: single precision resolves the cell to ~1e-7 of its size
-// wherever it lies in the domain (fp64 -> fp32 of the plain plane coefficients would resolve 1e-7 of the
-// DOMAIN).  Faces in walk order as in CellRecord.  w[0..2]: neighbours behind the three slots a ray can
-// leave through (walking up: slots 0..2, the upper candidates; walking down: slots 1..3), 28-bit ids;
-// w[0] bits 30-31: number of upper slots; w[3] = col0 | row0 << 16 (global row).
-struct alignas(16) GeoRecord {
-    float plane[4][3];
-    uint32_t w[4];
-};
-static_assert(sizeof(GeoRecord) == 64, "GeoRecord is half a 128-byte line");
-// 16 bytes of optics: unclamped alpha (tau), clamped alpha (0 below DBL_EPSILON: the cell neither absorbs nor
-// emits, line.cpp:220-224) and the source function Q / alpha_c.
-struct alignas(16) OptRecord {
-    float alpha_raw, alpha_c, source, pad;
-};
-static_assert(sizeof(OptRecord) == 16, "OptRecord is 16 bytes");
-
 // A place where a ray enters the grid through a boundary face.  first[pixel] holds a pixel's first
 // entry; further ones live in the overflow pool, chained through `next` (pool slot + 1, 0 = end).
 // z: the entry face's own depth at the pixel.  cell: bits 0-27 the cell, bits 28-31 k: the entry is KEYED at its
@@ -154,8 +132,11 @@ struct alignas(128) FrameCounters {
     unsigned long long covered;
     unsigned long long solid_pixels;
     unsigned long long entries;
-    unsigned int walk_overflow;
-    unsigned int entry_overflow;  // shard 0: boundary entries that found no slot in the overflow pool this frame
+    // shard 0 only, three adjacent words = a frame's status (c_api.hip reads them behind a frame delivered to host memory):
+    unsigned int walk_overflow;   // rays that hit the step bound
+    unsigned int entry_overflow;  // boundary entries that found no slot in the overflow pool this frame
+    unsigned int overlap_rays;    // rays that had to SKIP a boundary entry lying inside a stretch they had walked: cells of two
+                                  // components interpenetrate there (walk_common.hpp: next_entry) - not a grid a walk can render
     unsigned int odd_pixels;  // bin_sort_resolve: (pixel, cell) pairs with an odd number of covering faces
     unsigned int pool_used;   // per shard: slots asked of this shard's part of the overflow pool (may exceed the part)
 };

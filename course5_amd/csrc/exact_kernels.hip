@@ -510,7 +510,10 @@ void launch_resolve(hipStream_t s, const GridView& g, const ImageParams& im, con
 
 size_t segment_bytes() { return sizeof(Segment); }
 
-__global__ __launch_bounds__(128) void clear_walk_counters(FrameCounters* __restrict__ counters, uint32_t* __restrict__ sb, int n_sb) {
+// `raster_from`: the counters of the frame whose raster built the entry lists this frame reuses, if they are not
+// `counters` themselves (frames delivered to host memory keep their statistics per frame): its share is copied over.
+__global__ __launch_bounds__(128) void clear_walk_counters(FrameCounters* __restrict__ counters, uint32_t* __restrict__ sb, int n_sb,
+                                                           const FrameCounters* __restrict__ raster_from) {
     const int i = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
     if (sb && i < n_sb) sb[i] = 0u;
     if (i < kCounterShards) {
@@ -521,13 +524,19 @@ __global__ __launch_bounds__(128) void clear_walk_counters(FrameCounters* __rest
         c.solid_pixels = 0;
         c.entries = 0;
         c.walk_overflow = 0;
+        c.overlap_rays = 0;
         c.odd_pixels = 0;
+        if (raster_from) {
+            c.entry_overflow = raster_from[i].entry_overflow;
+            c.pool_used = raster_from[i].pool_used;
+        }
     }
 }
 
-void launch_clear_walk_counters(hipStream_t s, FrameCounters* counters, uint32_t* sb, int n_sb) {
+void launch_clear_walk_counters(hipStream_t s, FrameCounters* counters, uint32_t* sb, int n_sb, const FrameCounters* raster_from) {
     const int n = std::max(kCounterShards, sb ? n_sb : 0);
-    hipLaunchKernelGGL(clear_walk_counters, dim3(static_cast<unsigned>((n + 127) / 128)), dim3(128), 0, s, counters, sb, n_sb);
+    hipLaunchKernelGGL(clear_walk_counters, dim3(static_cast<unsigned>((n + 127) / 128)), dim3(128), 0, s, counters, sb, n_sb,
+                       raster_from == counters ? nullptr : raster_from);
 }
 
 void launch_transform_soa(hipStream_t s, const double* px, const double* py, const double* pz,

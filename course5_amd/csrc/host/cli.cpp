@@ -41,6 +41,7 @@ const option_spec kOptions[] = {
     {"bench_files", 0, false, "--bench: write every timed frame to <destination>_NNNNN.vti like a sweep (end to end with files)", nullptr},
     {"bench", 0, true, "render this many sweep frames without writing files and print one JSON line", nullptr},
     {"bench_warmup", 0, true, "untimed frames before --bench", "20"},
+    {"bench_rounds", 0, true, "--bench: the timed run is repeated this many times; the line carries the whole run, the fastest and the median round", "1"},
     {"auto_bounds", 0, false, "image domain = bounding box of the transformed objects instead of the fixed domain", nullptr},
     {"no_solids", 0, false, "do not generate the Roche lobe and the accretor sphere", nullptr},
     {"stats", 0, false, "print per-stage GPU timings and segment counts", nullptr},
@@ -136,6 +137,7 @@ bool program_options(int argc, char** argv, std::ostream& out) {
         else if (n == "bench_files") cfg.bench_files = true;
         else if (n == "bench") cfg.bench = static_cast<std::size_t>(std::max(0ll, to_integer(n, v)));
         else if (n == "bench_warmup") cfg.bench_warmup = static_cast<std::size_t>(std::max(0ll, to_integer(n, v)));
+        else if (n == "bench_rounds") cfg.bench_rounds = static_cast<std::size_t>(std::max(1ll, to_integer(n, v)));
         else if (n == "auto_bounds") cfg.auto_bounds = true;
         else if (n == "no_solids") cfg.no_solids = true;
         else if (n == "stats") cfg.print_stats = true;

@@ -32,6 +32,7 @@ struct render_config {
     bool auto_bounds = false;     // image domain = bounding box of the transformed objects (plane.cpp:278-288) instead of main.cpp:83's
     std::size_t bench = 0;        // > 0: render this many frames of the sweep without writing files, print one JSON line
     std::size_t bench_warmup = 20;
+    std::size_t bench_rounds = 1;
     bool no_solids = false;
     bool print_stats = false;
     bool parse_only = false;      // read the input, generate the solids, report sizes, no GPU work

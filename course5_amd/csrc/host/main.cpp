@@ -4,6 +4,7 @@
 #include <omp.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -116,8 +117,10 @@ private:
         item it;
         while (_queue.pop(it)) {
             try {
-                if (!_error) write_frame(it.img, it.name);
-                ++_written;
+                if (!_error) {
+                    write_frame(it.img, it.name);
+                    ++_written;  // (files really written: nothing is counted after a failure)
+                }
             } catch (...) {
                 if (!_error) _error = std::current_exception();
             }
@@ -140,9 +143,13 @@ struct frame_job {
 };
 class plane_driver {
 public:
-    plane_driver(plane& p, std::size_t depth, frame_writer* writer, const render_config& config, bool stats_between)
-        : _plane(p), _depth(depth), _writer(writer), _config(config), _stats_between(stats_between), _jobs(2 * depth + 2),
-          _thread([this] { run(); }) {}
+    // `failed`: shared by the drivers of a sweep and the thread that deals the frames - set by the first driver that throws,
+    // so that the others stop issuing and the dealing loop stops dealing (a failing GPU is reported at once, not after the
+    // rest of the sweep has been rendered and written)
+    plane_driver(plane& p, std::size_t depth, frame_writer* writer, const render_config& config, bool stats_between,
+                 std::atomic<bool>& failed)
+        : _plane(p), _depth(depth), _writer(writer), _config(config), _stats_between(stats_between), _failed(failed),
+          _jobs(2 * depth + 2), _thread([this] { run(); }) {}
     ~plane_driver() {
         _jobs.close();
         if (_thread.joinable()) _thread.join();
@@ -170,6 +177,7 @@ private:
         try {
             frame_job job;
             while (_jobs.pop(job)) {
+                if (_failed.load(std::memory_order_relaxed)) continue;  // another driver failed: drain the queue, issue nothing
                 while (_flight.size() >= _depth) retire();
                 _plane.set_views(job.views);
                 _plane.find_intersections();
@@ -178,6 +186,7 @@ private:
             while (!_flight.empty()) retire();
         } catch (...) {
             _error = std::current_exception();
+            _failed.store(true, std::memory_order_relaxed);
             frame_job drop;
             while (_jobs.pop(drop)) {}  // keep the dealing thread from blocking on a full queue
         }
@@ -187,6 +196,7 @@ private:
     frame_writer* _writer;
     const render_config& _config;
     bool _stats_between;
+    std::atomic<bool>& _failed;
     channel<frame_job> _jobs;
     std::deque<frame_job> _flight;
     std::exception_ptr _error;
@@ -361,14 +371,18 @@ int main(int argc, char** argv) try {
                           : config.sweep == "D" ? &view.donor_angle
                           : config.sweep == "I" ? &view.system_initial_angle_around_y
                                                 : &view.angle_around_y;
+    // Test hook, read from the environment by the product binary on purpose (tests/test_cli_gpu.py drives the real `course`):
+    // C5_TEST_STATS_BETWEEN makes every driver call count_all_intersections() between issue and retire, the place the
+    // reference allows it; it changes no result.  (C5_TEST_ENTRY_POOL, plane.cpp, starts the entry pool small likewise.)
     const bool stats_between = std::getenv("C5_TEST_STATS_BETWEEN") != nullptr;
     auto run_frames = [&](std::size_t first, std::size_t count, bool advance, bool write) {
         std::unique_ptr<frame_writer> writer;
         if (write) writer = std::make_unique<frame_writer>(static_cast<int>(std::max<std::size_t>(1, config.threads)));
         {
+            std::atomic<bool> failed{false};
             std::vector<std::unique_ptr<plane_driver>> drivers;
-            for (auto& p : planes) drivers.push_back(std::make_unique<plane_driver>(*p, per_plane, writer.get(), config, stats_between));
-            for (std::size_t k = first; k < first + count; ++k) {
+            for (auto& p : planes) drivers.push_back(std::make_unique<plane_driver>(*p, per_plane, writer.get(), config, stats_between, failed));
+            for (std::size_t k = first; k < first + count && !failed.load(std::memory_order_relaxed); ++k) {
                 if (advance) *swept += config.sweep_step;
                 apply_view(objects[0], roche_lobe ? &objects[1] : nullptr);
                 frame_job job;
@@ -408,25 +422,37 @@ int main(int argc, char** argv) try {
     } else {
         // --bench: frames rendered and delivered to host memory, no files — or, with --bench_files, written like a
         // sweep's (end to end: render + copy + deflate + file).  One JSON line.
-        run_frames(0, config.bench_warmup, false, false);
+        // --bench_rounds R: the timed run is repeated R times (each `bench` frames, each timed on its own): the line carries the
+        // whole run's figure and the fastest and the median round, so that a reader sees the spread and not one draw.
+        run_frames(0, config.bench_warmup, false, config.bench_files);  // warm-up through the same path (writer thread, files)
         std::size_t retries0 = 0;
         for (const auto& p : planes) retries0 += p->retries();
-        const auto b0 = std::chrono::steady_clock::now();
-        run_frames(0, config.bench, config.sweep_step != 0.0, config.bench_files);
-        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - b0).count();
+        const std::size_t rounds = std::max<std::size_t>(1, config.bench_rounds);
+        std::vector<double> round_ms;
+        double secs = 0.0;
+        for (std::size_t r = 0; r < rounds; ++r) {
+            const auto b0 = std::chrono::steady_clock::now();
+            run_frames(0, config.bench, config.sweep_step != 0.0, config.bench_files);
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - b0).count();
+            secs += dt;
+            round_ms.push_back(dt * 1e3 / static_cast<double>(config.bench));
+        }
+        std::sort(round_ms.begin(), round_ms.end());
+        const double frames_timed = static_cast<double>(config.bench) * static_cast<double>(rounds);
         std::size_t retries1 = 0, moved = 0;
         for (const auto& p : planes) retries1 += p->retries(), moved += p->rebalances();
         const double rays = static_cast<double>(config.resolution_x) * static_cast<double>(config.resolution_y);
         std::string rows = "[";
         for (const auto& b : base_plane.row_blocks()) rows += (rows.size() > 1 ? ", " : "") + std::to_string(b.second);
         rows += "]";
-        std::printf("{\"course_bench\": {\"frames\": %zu, \"warmup\": %zu, \"ms_per_frame\": %.4f, \"mrays_per_s\": %.1f, \"frames_per_s\": %.2f, "
+        std::printf("{\"course_bench\": {\"frames\": %zu, \"rounds\": %zu, \"warmup\": %zu, \"ms_per_frame\": %.4f, \"ms_per_frame_min\": %.4f, "
+                    "\"ms_per_frame_median\": %.4f, \"mrays_per_s\": %.1f, \"frames_per_s\": %.2f, "
                     "\"res_x\": %zu, \"res_y\": %zu, \"n_devices\": %zu, \"split\": \"%s\", \"exchange\": \"%s\", \"row_layout\": \"%s\", "
                     "\"rows_per_device\": %s, \"rebalances\": %zu, "
                     "\"sweep\": \"%s\", \"sweep_step\": %g, \"solids\": %s, \"retries\": %zu, "
                     "\"delivered_to\": \"%s\"}}\n",
-                    config.bench, config.bench_warmup, secs * 1e3 / static_cast<double>(config.bench),
-                    rays * static_cast<double>(config.bench) / secs / 1e6, static_cast<double>(config.bench) / secs,
+                    config.bench, rounds, config.bench_warmup, secs * 1e3 / frames_timed, round_ms.front(), round_ms[round_ms.size() / 2],
+                    rays * frames_timed / secs / 1e6, frames_timed / secs,
                     config.resolution_x, config.resolution_y, devices.size(),
                     devices.size() == 1 ? "none" : (by_frames ? "frames" : "rows"), by_frames ? "none" : config.exchange.c_str(),
                     (devices.size() == 1 || by_frames) ? "none" : (layout == row_layout::blocks ? "blocks" : "tiles"), rows.c_str(), moved,

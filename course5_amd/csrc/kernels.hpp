@@ -19,22 +19,12 @@ struct GridView {  // device pointers of the persistent grid + per-view buffers
     const double *alpha = nullptr, *q = nullptr;
     const uint32_t* bface = nullptr;
     ExitRecord* xrec = nullptr;  // fp64 walk: one 128-byte line per cell and view (exit candidates + optics)
-    CellRecord* rec = nullptr;   // the same allocation seen as the mixed walk's SteepPlanes slots ("precision" 1)
-    // "precision" 1 (walk_mixed.hip): compact single-precision records instead of rec / opt
-    GeoRecord* geo = nullptr;
-    OptRecord* opt32 = nullptr;
-    float* z0 = nullptr;
     // only cells whose projected y-extent meets [cull_y_lo, cull_y_hi] can be reached by a ray of this context
     double cull_y_lo = 0, cull_y_hi = 0;
 };
 
 struct WalkParams {
     const ExitRecord* xrec;
-    const CellRecord* rec;      // "precision" 1: SteepPlanes
-    const GeoRecord* geo;       // "precision" 1
-    const OptRecord* opt32;
-    const float* z0;
-    int32_t precision;          // 0: fp64 walk (bit-faithful), 1: walk_composite_mixed
     EntryHead* entry_head;      // [n_local_px] entries of the pixel + overflow chain; the walk hands it back zeroed
     const Entry* entry_first;   // [n_local_px] first entry (valid where entry_count > 0)
     const Entry* entry_pool;    // overflow entries, chained from entry_first[].next
@@ -71,7 +61,8 @@ struct WalkParams {
     // 1: the walk leaves the per-pixel entry heads as they are (it normally hands them back cleared): the next frame has
     // the same view and reuses the entry lists, the records and the transformed vertices (c_api.hip: "view_cache")
     int32_t keep_entries;
-    unsigned* sticky;           // [0] largest entry total, [1] rays over the step bound; reset by the host only
+    unsigned* sticky;           // [0] entries without a pool slot, [1] rays over the step bound, [2] rays that skipped an entry
+                                // (interpenetrating components), summed over the frames since the host last looked; reset by the host only
 };
 
 // exact_kernels.hip (-ffp-contract=off)
@@ -79,7 +70,9 @@ struct WalkParams {
 // sb_cost_to_clear: the walk's per-row costs (WalkParams::sb_cost), n_sb of them, cleared by the same launch
 // A frame that reuses the per-view data of the frame before: only what the walk adds to is cleared (the raster's part of
 // the counters - pool_used, entry_overflow - stays), and the walk's per-row costs
-void launch_clear_walk_counters(hipStream_t s, FrameCounters* counters, uint32_t* sb_cost_to_clear, int n_sb);
+// raster_from: where the raster's share of those counters stands, if not in `counters` itself (nullptr: it does)
+void launch_clear_walk_counters(hipStream_t s, FrameCounters* counters, uint32_t* sb_cost_to_clear, int n_sb,
+                                const FrameCounters* raster_from = nullptr);
 void launch_transform_soa(hipStream_t s, const double* px, const double* py, const double* pz,
                           double* vx, double* vy, double* vz, int64_t n, const RotationList& R,
                           FrameCounters* counters_to_clear, uint32_t* sb_cost_to_clear = nullptr, int n_sb = 0);
@@ -110,8 +103,7 @@ void launch_mask_overlay(hipStream_t s, const uint32_t* src, uint32_t* dst, int6
 // key_slack of the two launchers below: how far an entry's depth key lies behind its face (walk_common.hpp:
 // entry_key_slack) = this fraction of the diagonal of the grid's bounding box (+ a term for the rounding of an
 // absolute depth, c_api.hip), the same for every face of a frame
-constexpr double kEntryKeySlack = 0x1p-24;       // fp64 walk
-constexpr double kEntryKeySlackMixed = 0x1p-13;  // "precision" 1: exit depths carry fp32 rounding
+constexpr double kEntryKeySlack = 0x1p-24;
 void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, int order);
 void launch_entry_lists(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
                         const ImageParams& im, EntryHead* head, Entry* first, Entry* pool, int64_t capacity,
@@ -121,11 +113,5 @@ void launch_setup_fused(hipStream_t s, const GridView& g, double alpha_limit, in
                         const ImageParams& im, EntryHead* head, Entry* first, Entry* pool, int64_t capacity,
                         FrameCounters* counters, unsigned* sticky, int want_upper, double key_slack);
 void launch_walk(hipStream_t s, const WalkParams& p, int tile_shape);
-
-// walk_mixed.hip ("precision" 1)
-void launch_build_records_mixed(hipStream_t s, const GridView& g, const ImageParams& im, const double* Xtab,
-                                const double* Ytab, double alpha_limit, int order, double steep_ratio, bool with_optics);
-void launch_walk_mixed(hipStream_t s, const WalkParams& p, int tile_shape);
-bool mixed_precision_fits(int64_t n_cells, const ImageParams& im);
 
 }  // namespace c5

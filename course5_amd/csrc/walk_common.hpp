@@ -1,5 +1,5 @@
-// Device helpers shared by the walk kernels (walk_kernels.hip: fp64, bit-faithful; walk_mixed.hip: fp32
-// geometry with fp64 accumulators): face planes and per-cell records, tile shapes, exp, entry lists.
+// Device helpers of the walk kernels (walk_kernels.hip, fp64): face planes and per-cell records, tile shapes, exp,
+// entry lists.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -324,10 +324,21 @@ __device__ __forceinline__ EntryHead load_entry_head(const EntryHead* p) {
 // key beyond where the ray left the grid" finds the abutting cell whichever way the rounding fell, and never an entry
 // already used: w_cur is moved to the key taken, and keys are compared strictly.
 // On return w_entry = the entry's OWN depth (where the chord through its cell starts).
+//
+// Interpenetrating components (round 4).  Two parts of a grid that share no face but overlap in space — the reference bins
+// and sorts any soup (plane.cpp:184-192, line.cpp:138) — cannot be walked: inside the overlap a ray is in two cells at
+// once.  Connectivity does not show it, but the entry lists do: such a ray meets a boundary entry INSIDE a stretch it
+// has just walked through cells (between the key of the entry it took last, w_taken, and where it left the grid, w_cur),
+// an entry it can never take.  `skipped` is set for it (a margin of two slacks either side keeps the twin entries of a
+// pixel centre exactly on the common edge of two boundary faces, and the abutting entry of a hanging-node interface,
+// out of it); the walk counts such rays, and the host answers with C5_RETRY and renders the grid with bin_sort_resolve
+// from then on (c_api.hip: finish_frame).  Only on the (re-)entry path: nothing is added to a step.
 template <bool kUp>
-__device__ __forceinline__ int next_entry(const WalkParams& P, size_t lp, EntryHead h, double& w_cur, double& w_entry) {
+__device__ __forceinline__ int next_entry(const WalkParams& P, size_t lp, EntryHead h, double& w_cur, double& w_entry,
+                                          double w_taken, bool& skipped) {
     double key_best = DBL_MAX;
     int cell = -1;
+    const double margin = 2.0 * P.key_slack;
     const Entry* e = P.entry_first + lp;
     int hop = h.chain;
     for (int k = 0; k < h.count; ++k) {  // bounded by the count: a chain cut short by a pool overflow ends at hop 0
@@ -340,6 +351,7 @@ __device__ __forceinline__ int next_entry(const WalkParams& P, size_t lp, EntryH
             cell = static_cast<int>(word & kIdMask);
             w_entry = we;
         }
+        if (key > w_taken + margin && key < w_cur - margin) skipped = true;
         if (hop <= 0 || hop > P.pool_capacity) break;
         e = P.entry_pool + (hop - 1);
         hop = e->next;
@@ -365,11 +377,10 @@ __device__ __forceinline__ int next_entry(const WalkParams& P, size_t lp, EntryH
 //   * uniform: keys shifted by the same amount keep the order of the true depths, so the walk takes a ray's entries in
 //     exactly their order whatever the size of the slack — also a stretch of grid thinner than the slack that is
 //     followed by another entry within it (a first version with a slack per face, proportional to the face's extent,
-//     swapped two such entries in one fuzz scene in 400: a 4.6e-7 chord lost, S off by one; in the mixed walk, whose
-//     slack is larger, 8 in 400).  It only has to exceed the rounding between two evaluations of one plane from
-//     different vertex triples: `base` = 2^-24 of the grid's bounding-box diagonal for the fp64 walk (1e-7 on the C3
-//     grid, 1e5 times that rounding), 2^-13 for the mixed walk, whose exit depths carry fp32 rounding of the cell's
-//     size and of the absolute depth (c_api.hip).  Tied to the GRID's size: a slack longer than a whole ray would let
+//     swapped two such entries in one fuzz scene in 400: a 4.6e-7 chord lost, S off by one).  It only has to exceed
+//     the rounding between two evaluations of one plane from different vertex triples: `base` = 2^-24 of the grid's
+//     bounding-box diagonal (1e-7 on the C3 grid, 1e5 times that rounding; c_api.hip).  Tied to the GRID's size: a
+//     slack longer than a whole ray would let
 //     a pixel that two boundary faces both claim (centre exactly on their common edge) walk the same cells twice.
 //   * steep faces: a plane's depth is c + gx x + gy y with |gx x| of the size kappa * |x|: rounding eps * kappa * |x|,
 //     and kappa * (the relative error of gx) * extent = eps * kappa^2 * extent on top, kappa^2 = 1 + gx^2 + gy^2

@@ -1,8 +1,9 @@
 // gfx950 kernels of the render hot path (fp64; FMA contraction allowed here).
 //
-//   build_records    per view: cell -> 128-byte walk record (four face planes about a cell-local
-//                    origin, neighbour ids, orientation flags) + 32-byte optics record.
-//                    Replaces the per-segment plane solve line::find_polygon_intersection_z
+//   build_records    per view: cell -> ONE 128-byte ExitRecord (device_types.hpp): the (up to three) planes a ray
+//                    can LEAVE the cell through, in the walk coordinate about the absolute pixel coordinates, the
+//                    neighbour words behind them, and the cell's optics (alpha, clamped alpha, 1 / alpha or Q / alpha,
+//                    Q).  Replaces the per-segment plane solve line::find_polygon_intersection_z
 //                    (line.cpp:150-174) and the per-step clamp/divide of
 //                    line::integrate_ray_value_by_i (line.cpp:213-224).
 //   entry_raster     boundary faces facing the viewer -> per-pixel entry records (CSR).
@@ -223,6 +224,8 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
     const bool in_image = (col < im.res_x) && (lrow < im.n_local_rows);
 
     unsigned n_seg = 0, n_step = 0, is_solid = 0, overflow = 0;
+    bool skipped = false;       // the ray met an entry inside a stretch it had walked (next_entry): interpenetrating components
+    double w_taken = -DBL_MAX;  // key of the entry the ray took last
     double tau = 0.0, I = 0.0, T = 1.0;
     double x = 0.0, y = 0.0, w_cur = -DBL_MAX, carry = 0.0;  // carry: the depth (walk coordinate) at which the ray entered the current cell
     EntryHead ent{0, 0};
@@ -246,7 +249,8 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
             y = P.Ytab[global_row_of(im, lrow)];
             // touched once per frame: keep them from displacing the cell records in L2 / Infinity Cache
             ent = load_entry_head(P.entry_head + lp);
-            if (ent.count > 0) cell = next_entry<kUp>(P, lp, ent, w_cur, carry);
+            if (ent.count > 0) cell = next_entry<kUp>(P, lp, ent, w_cur, carry, w_taken, skipped);
+            w_taken = w_cur;
         }
     }
 
@@ -273,7 +277,8 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
             overflow = 1;
             nb = -1;
         } else if (nb < 0 && !overflow) {
-            nb = next_entry<kUp>(P, lp, ent, w_cur, carry_next);  // left the grid: re-entry of a non-convex grid?
+            nb = next_entry<kUp>(P, lp, ent, w_cur, carry_next, w_taken, skipped);  // left the grid: re-entry of a non-convex grid?
+            w_taken = w_cur;
         }
 
         // issue the next cell's loads now; the arithmetic below does not depend on them
@@ -324,15 +329,20 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
     const unsigned s_sol = wave_sum_u32(is_solid);
     const unsigned s_ovf = wave_sum_u32(overflow);
     const unsigned s_ent = wave_sum_u32(static_cast<unsigned>(ent.count));
+    const unsigned s_skip = static_cast<unsigned>(__popcll(__builtin_amdgcn_ballot_w64(skipped)));
     if (lane == 0) {
+        if (s_skip) {
+            atomicAdd(&P.counters->overlap_rays, s_skip);
+            atomicAdd(P.sticky + 2, s_skip);
+        }
         FrameCounters* const fc = P.counters + ((blockIdx.x * 4u + static_cast<unsigned>(threadIdx.x >> 6)) % kCounterShards);
         if (s_ent) atomicAdd(&fc->entries, static_cast<unsigned long long>(s_ent));
         if (s_seg) atomicAdd(&fc->segments, static_cast<unsigned long long>(s_seg));
         if (s_step) atomicAdd(&fc->steps, static_cast<unsigned long long>(s_step));
         if (s_cov) atomicAdd(&fc->covered, static_cast<unsigned long long>(s_cov));
         if (s_sol) atomicAdd(&fc->solid_pixels, static_cast<unsigned long long>(s_sol));
-        if (s_ovf) {
-            atomicAdd(&fc->walk_overflow, s_ovf);
+        if (s_ovf) {  // (shard 0, beside entry_overflow: the two words a frame's status is read from; rare, never contended)
+            atomicAdd(&P.counters->walk_overflow, s_ovf);
             atomicAdd(P.sticky + 1, s_ovf);
         }
     }
@@ -503,6 +513,7 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
     const char* const rec_bytes = reinterpret_cast<const char*>(P.xrec);
 
     constexpr unsigned kOverflowBit = 0x80000000u;  // of n_seg: the ray hit the step bound
+    constexpr unsigned kSkippedBit = 0x40000000u;   // of n_seg: the ray met an entry inside a stretch it had walked (next_entry)
     unsigned n_seg = 0;
     unsigned n_step_wave = 0;  // wave-uniform: lane-steps taken by the whole wavefront
     double tau = 0.0, I = 0.0, T = 1.0;
@@ -534,7 +545,8 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
             x = P.Xtab[pixel_col()];
             y = P.Ytab[global_row_of(im, pixel_lrow())];
             double w_cur = -DBL_MAX;
-            if (ent.count > 0) nb = next_entry<kUp>(P, lp, ent, w_cur, carry);
+            bool skipped = false;
+            if (ent.count > 0) nb = next_entry<kUp>(P, lp, ent, w_cur, carry, -DBL_MAX, skipped);
             my_scur[lane] = w_cur;
         }
     }
@@ -808,9 +820,12 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
             int nxt = static_cast<int>(id);
             if (id == kNoCell) {  // left the grid: re-entry of a non-convex grid?
                 const size_t lp = pixel_index();
-                double w_cur = my_scur[lane];
+                double w_cur = my_scur[lane];  // (the key of the entry the ray took last: only (re-)entries write it)
+                const double w_taken = w_cur;
+                bool skipped = false;
                 if (has_exit) w_cur = fmax(w_cur, sg.w_exit);
-                nxt = next_entry<kUp>(P, lp, load_entry_head(P.entry_head + lp), w_cur, carry);
+                nxt = next_entry<kUp>(P, lp, load_entry_head(P.entry_head + lp), w_cur, carry, w_taken, skipped);
+                if (skipped) n_seg |= kSkippedBit;
                 my_scur[lane] = w_cur;
             }
 #if C5_WALK_STAMPS > 1
@@ -870,7 +885,8 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
     }
 
     const unsigned overflow = n_seg >> 31;
-    n_seg &= ~kOverflowBit;
+    const bool skipped = (n_seg & kSkippedBit) != 0u;
+    n_seg &= ~(kOverflowBit | kSkippedBit);
     unsigned is_solid = 0, n_entries = 0;
     if (in_image) {
         const size_t lp = pixel_index();
@@ -903,7 +919,12 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
     const unsigned s_sol = wave_sum_u32(is_solid);
     const unsigned s_ovf = wave_sum_u32(overflow);
     const unsigned s_ent = wave_sum_u32(n_entries);
+    const unsigned s_skip = static_cast<unsigned>(__popcll(__builtin_amdgcn_ballot_w64(skipped)));
     if (lane == 0) {
+        if (s_skip) {
+            atomicAdd(&P.counters->overlap_rays, s_skip);
+            atomicAdd(P.sticky + 2, s_skip);
+        }
         FrameCounters* const fc = P.counters + ((blockIdx.x * 4u + static_cast<unsigned>(wave)) % kCounterShards);
         if (s_seg && P.sb_cost && P.xcd_mode == 2) {  // what this wavefront cost, to its row of super-blocks
             const int sb_row = ty / P.band_tiles;
@@ -914,8 +935,8 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
         if (n_step_wave) atomicAdd(&fc->steps, static_cast<unsigned long long>(n_step_wave));
         if (s_cov) atomicAdd(&fc->covered, static_cast<unsigned long long>(s_cov));
         if (s_sol) atomicAdd(&fc->solid_pixels, static_cast<unsigned long long>(s_sol));
-        if (s_ovf) {
-            atomicAdd(&fc->walk_overflow, s_ovf);
+        if (s_ovf) {  // (shard 0, beside entry_overflow: the two words a frame's status is read from; rare, never contended)
+            atomicAdd(&P.counters->walk_overflow, s_ovf);
             atomicAdd(P.sticky + 1, s_ovf);
         }
     }

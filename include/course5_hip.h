@@ -150,17 +150,6 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  once the transmittance T falls below "transmittance_cutoff" (default 1e-12,
  *                  0 disables).  Both agree to rounding wherever the reference's recurrence is
  *                  well conditioned (it is not for DBL_EPSILON <= alpha < ~1e-8).
- *   "precision"    0 (default): the fp64 walk — images equal the reference's to the last bit of their fp32
- *                  values, segment counts equal plane::count_all_intersections.  1: fp32 face planes about a
- *                  cell-local origin on the pixel lattice (64-byte records), fp32 series for exp(-alpha dz) - 1,
- *                  fp64 only for the tau and I accumulators: within the 1e-5 bar on every fixture (about 1e-6 in
- *                  practice); not bit-faithful, and NOT robust where fp32 cannot tell two exit faces apart: a ray
- *                  within ~1e-8 of a projected edge may count a sliver more or less than the reference, and if that
- *                  edge lies on the grid's boundary it can take the wrong face out of the grid and lose the rest of
- *                  the ray (randomised sweep, round 3: 1 ray in 1.4e7; single pixels at 1e-4 in 3 scenes of 3 000).
- *                  No faster than the fp64 walk since round 3: use the default.
- *   "steep_ratio"  "precision" 1: a cell whose fp32 plane terms exceed this many times its extent along the rays is
- *                  evaluated from its fp64 record instead (default 64; 0: never).
  *   "algorithm"    0 (default for conforming grids): face-adjacency walk.  1: bin_sort_resolve, the
  *                  reference's own algorithm on the GPU (every face of every cell scan-converted onto
  *                  the pixels, per-pixel sort by z, integrate) — handles tet soups, overlapping and
@@ -174,10 +163,6 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *   "cost_order"   1 (default): frames with fewer rays than about two rounds of the GPU's wavefront slots start the rows of
  *                  their image dearest first (by the cost per row of the last frame the caller waited for) instead
  *                  of top to bottom; 0: always top to bottom.  Same results.
- *   "optics_once"  "precision" 1 only (the fp64 walk's 128-byte exit records carry the optics and are rebuilt whole every
- *                  view).  1 (default): a cell's optics (alpha, clamped alpha, its reciprocal, Q: nothing of the view) are
- *                  rebuilt only after c5_upload_grid / c5_update_scalars or a change of the alpha limit or "integration",
- *                  not every frame; 0: every frame.  Same results.
  *   "stage_slots"  "lds_stage" 1 / 2: distinct cells staged per wavefront and step (LDS-DMA passes of seven).  0 (default): 21
  *                  when the frame before had fewer than 120 ray-cell segments per cell (pixels coarse against the cells:
  *                  more distinct cells per 8x8 tile), else 14 (one more wavefront per SIMD); 14 / 21: fixed.  Same results

@@ -1,5 +1,5 @@
 """A/B of two builds of the library in ONE process, runs interleaved (A B A B ...), so that clock and temperature
-drift hits all alike.  usage: ab_probe.py libA.so libB.so [libC.so ...] [precision] [rounds] [workload]"""
+drift hits all alike.  usage: ab_probe.py libA.so libB.so [libC.so ...] [rounds] [workload]"""
 import os
 import sys
 import torch
@@ -8,9 +8,8 @@ from course5_amd import capi, meshgen as mg  # noqa: E402
 
 paths = [a for a in sys.argv[1:] if a.endswith(".so")]
 rest = [a for a in sys.argv[1:] if not a.endswith(".so")]
-precision = int(rest[0]) if len(rest) > 0 else 0
-rounds = int(rest[1]) if len(rest) > 1 else 5
-workload = rest[2] if len(rest) > 2 else "c3"
+rounds = int(rest[0]) if len(rest) > 0 else 5
+workload = rest[1] if len(rest) > 1 else "c3"
 res = {"c3": (2400, 1800), "c2": (1200, 900), "c3@1200": (1200, 900), "c3@4800": (4800, 3600)}[workload]
 xyz, cells, alpha, q = mg.workload(workload.split("@")[0])
 out = torch.zeros((res[1], res[0], 2), dtype=torch.float32, device="cuda:0")
@@ -24,7 +23,6 @@ for p in paths:
     ctx.set_image(res[0], res[1], mg.REFERENCE_BOUNDS)
     ctx.set_view(mg.view_rotations(**mg.BENCH_VIEW))
     ctx.set_option("stage_timing", 0)
-    ctx.set_option("precision", precision)
     for kv in os.environ.get("C5_OPTS", "").split(","):  # e.g. C5_OPTS=lds_stage=2,band_rows=64
         if kv:
             ctx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
@@ -48,4 +46,4 @@ for r in range(rounds):
         tot[k] += ms
         line.append("%s %.4f" % (paths[k].split("/")[-1], ms))
     print("round", r, " | ".join(line), flush=True)
-print("precision", precision, "mean walk ms:", " | ".join("%s %.4f" % (paths[k].split("/")[-1], tot[k] / rounds) for k in range(len(paths))))
+print("mean walk ms:", " | ".join("%s %.4f" % (paths[k].split("/")[-1], tot[k] / rounds) for k in range(len(paths))))

@@ -9,10 +9,8 @@ ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$ROOT/gpurun_out"
 export TMPDIR=/tmp
 cd "$ROOT" || exit 1
-# PRECISION=1 profiles walk_composite_mixed (option "precision" 1) instead of the fp64 walk
 EXTRA=()
-[ -n "$PRECISION" ] && EXTRA=(--precision "$PRECISION")
-CMD=(python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-host-image --no-steady --no-mixed --no-native "${EXTRA[@]}")
+CMD=(python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-host-image --no-steady --no-native "${EXTRA[@]}")
 GROUPS_=(
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
   "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU"
@@ -25,7 +23,7 @@ GROUPS_=(
 rm -rf "$OUT"/pmc_* "$OUT"/prof_kt
 # the kernel trace runs the SAME command as the bench line (default steps / warmup), so that its average
 # kernel duration and bench.py's HIP-event figure describe the same sustained state
-rocprofv3 --kernel-trace --stats -d "$OUT/prof_kt" -o kt --output-format csv -- python3 bench.py --no-cpu-baseline --no-host-image --no-mixed --no-native "${EXTRA[@]}" > "$OUT/prof_kt.log" 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats -d "$OUT/prof_kt" -o kt --output-format csv -- python3 bench.py --no-cpu-baseline --no-host-image --no-native "${EXTRA[@]}" > "$OUT/prof_kt.log" 2>&1 || exit 1
 for g in "${GROUPS_[@]}"; do
   name="pmc_${g%% *}"
   # shellcheck disable=SC2086

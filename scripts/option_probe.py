@@ -1,5 +1,5 @@
 """A/B of one option of the library in ONE process, runs interleaved; also says whether the images are bit-equal.
-usage: option_probe.py NAME VALUE_A VALUE_B [rounds] [workload] [precision]"""
+usage: option_probe.py NAME VALUE_A VALUE_B [rounds] [workload]"""
 import sys
 import torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
@@ -8,7 +8,6 @@ from course5_amd import capi, meshgen as mg  # noqa: E402
 name, va, vb = sys.argv[1], float(sys.argv[2]), float(sys.argv[3])
 rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 workload = sys.argv[5] if len(sys.argv) > 5 else "c3"
-precision = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 res = {"c3": (2400, 1800), "c2": (1200, 900), "c3@1200": (1200, 900), "c3@4800": (4800, 3600)}[workload]
 xyz, cells, alpha, q = mg.workload(workload.split("@")[0])
 outs, ctxs = [], []
@@ -19,7 +18,6 @@ for v in (va, vb):
     ctx.set_image(res[0], res[1], mg.REFERENCE_BOUNDS)
     ctx.set_view(mg.view_rotations(**mg.BENCH_VIEW))
     ctx.set_option("stage_timing", 0)
-    ctx.set_option("precision", precision)
     ctx.set_option(name, v)
     ctxs.append(ctx)
     outs.append(torch.zeros((res[1], res[0], 2), dtype=torch.float32, device="cuda:0"))

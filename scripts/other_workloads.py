@@ -17,8 +17,8 @@ rows = [("C3 998 250-cell grid, 2400x1800 (the bench line)", os.path.join(ROOT, 
         ("config 5 on one GPU: 360 frames, lobe + sphere, -Y sweep", "c5_Y")]
 out = [f"# {tag}: other workloads on one MI355X (scripts/other_workloads.sh: python bench.py --no-cpu-baseline --no-native --steps 200 ...; "
        f"same build as {tag}_bench.json)", "",
-       "| workload | Mrays/s | ms per frame | walk kernel ms | mixed precision: Mrays/s | its walk kernel ms | delivered to host: Mrays/s | segments per frame |",
-       "|---|---|---|---|---|---|---|---|"]
+       "| workload | Mrays/s | ms per frame | walk kernel ms | delivered to host: Mrays/s | segments per frame |",
+       "|---|---|---|---|---|---|"]
 
 
 def last_json_line(path):
@@ -31,10 +31,9 @@ for name, f in rows:
     if not os.path.exists(path):
         continue
     d = last_json_line(path)
-    m = d.get("value_mixed_precision") or {}
     h = (d.get("value_host_image") or {}).get("pipelined") or {}
     fmt = lambda v, spec: format(v, spec) if v is not None else "-"  # noqa: E731
-    out.append(f"| {name} | {d['value']:.0f} | {d['ms_per_step']:.4f} | {d['roofline']['kernel_ms']:.4f} | {fmt(m.get('value'), '.0f')} | "
-               f"{fmt(m.get('kernel_ms'), '.4f')} | {fmt(h.get('value'), '.0f')} | {d['config']['segments_per_frame']} |")
+    out.append(f"| {name} | {d['value']:.0f} | {d['ms_per_step']:.4f} | {d['roofline']['kernel_ms']:.4f} | "
+               f"{fmt(h.get('value'), '.0f')} | {d['config']['segments_per_frame']} |")
 open(os.path.join(ROOT, "profiles", f"{tag}_other_workloads.md"), "w").write("\n".join(out) + "\n")
 print("\n".join(out))

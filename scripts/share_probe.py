@@ -25,24 +25,22 @@ def timed():
     return best
 
 
-lines = ["# r03: which walk kernel on a SMALL share of the frame (what one of 8 GPUs renders)?  `python scripts/share_probe.py`", "",
+lines = ["# r04: which walk kernel on a SMALL share of the frame (what one of 8 GPUs renders)?  `python scripts/share_probe.py`", "",
          "walk = best of 8 after 30 warm frames, HIP events; a share that fills a third of the wavefront slots lasts as long as one wavefront's life: "
          "steps x per-step latency, and a lone wavefront's step is no shorter than one among eight (1.1 us)", "",
-         "| image | rows (first, count) | lds_stage | tile | precision | walk ms | frame ms | covered pixels |", "|---|---|---|---|---|---|---|---|"]
+         "| image | rows (first, count) | lds_stage | tile | walk ms | frame ms | covered pixels |", "|---|---|---|---|---|---|---|"]
 for res, rows in (((2400, 1800), (838, 124)), ((2400, 1800), (0, 514)), ((2400, 1800), (776, 248)), ((4800, 3600), (1676, 248))):
     ctx.set_row_range(0, -1)
     ctx.set_image(res[0], res[1], mg.REFERENCE_BOUNDS)
     ctx.set_row_range(*rows)
-    for lds, tile, prec in ((2, 3, 0), (1, 3, 0), (0, 3, 0), (0, 0, 0), (0, 1, 0), (2, 0, 0), (2, 1, 0), (2, 3, 1)):
+    for lds, tile in ((2, 3), (1, 3), (0, 3), (0, 0), (0, 1), (2, 0), (2, 1)):
         ctx.set_option("lds_stage", lds)
         ctx.set_option("tile", tile)
-        ctx.set_option("precision", prec)
         st = timed()
-        print(f"{res[0]}x{res[1]} rows {rows}: lds_stage {lds} tile {tile} precision {prec}: walk {st['ms_walk']:.4f} ms, frame {st['ms_total']:.4f}, "
+        print(f"{res[0]}x{res[1]} rows {rows}: lds_stage {lds} tile {tile}: walk {st['ms_walk']:.4f} ms, frame {st['ms_total']:.4f}, "
               f"covered {st['covered_pixels']}", flush=True)
-        lines.append(f"| {res[0]}x{res[1]} | {rows} | {lds} | {tile} | {prec} | {st['ms_walk']:.4f} | {st['ms_total']:.4f} | {st['covered_pixels']} |")
-    ctx.set_option("precision", 0)
+        lines.append(f"| {res[0]}x{res[1]} | {rows} | {lds} | {tile} | {st['ms_walk']:.4f} | {st['ms_total']:.4f} | {st['covered_pixels']} |")
 
 from course5_amd.build import kernel_source_hash
 lines.insert(2, f"kernel sources {kernel_source_hash()}")
-open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_share_probe.md"), "w").write("\n".join(lines) + "\n")
+open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_share_probe.md"), "w").write("\n".join(lines) + "\n")

@@ -63,7 +63,7 @@ def write_roofline(tag, walk, c):
                             "bank_conflict_share": (get("SQ_LDS_BANK_CONFLICT") or 0.0) / get("SQ_LDS_IDX_ACTIVE")}
         if get("SQ_WAVE_CYCLES"):
             units["wave_slots"] = {"frac": 4.0 * get("SQ_WAVE_CYCLES") / (cycles * n_simd * 8),
-                                   "what": "4 x SQ_WAVE_CYCLES / (cycles x 8192 wavefront slots): average occupancy (the fp64 exit-record walk's 64 VGPRs and the mixed walk's 58 both allow all 8 per SIMD)"}
+                                   "what": "4 x SQ_WAVE_CYCLES / (cycles x 8192 wavefront slots): average occupancy (the exit-record walk's 62-64 VGPRs allow all 8 per SIMD)"}
         if get("SQ_WAIT_ANY") and get("SQ_WAVE_CYCLES"):
             units["waiting"] = {"frac": get("SQ_WAIT_ANY") / get("SQ_WAVE_CYCLES"),
                                 "what": "SQ_WAIT_ANY / SQ_WAVE_CYCLES: share of a wavefront's life parked on s_waitcnt"}

@@ -49,16 +49,6 @@ def test_random_scenes_match_the_oracle(gpu_ctx, oracle_port, block):
         tol = 1e-5 * np.maximum(np.abs(a), np.abs(b)) + 1e-6 * np.abs(b).max()
         assert int((np.abs(a - b) > tol).sum()) == 0, seed
         assert st["segments"] == ref["segments"] and st["covered_pixels"] == ref["covered"], seed
-        # the same scene with option "precision" 1 (fp32 planes, fp64 accumulators): the same 1e-5 bar; the segment
-        # count may differ by the few rays that graze a projected edge within ~1e-9
-        gpu_ctx.set_option("precision", 1)
-        img = gpu_ctx.render()
-        st = gpu_ctx.stats()
-        gpu_ctx.set_option("precision", 0)
-        a = img.astype(np.float64)
-        tol = 1e-5 * np.maximum(np.abs(a), np.abs(b)) + 1e-6 * np.abs(b).max()
-        assert int((np.abs(a - b) > tol).sum()) == 0, ("mixed", seed)
-        assert abs(st["segments"] - ref["segments"]) <= max(3, ref["segments"] // 5000), ("mixed", seed)
     gpu_ctx.set_option("lds_stage", 2)
     gpu_ctx.set_option("stage_slots", 0)
     gpu_ctx.set_option("integration", 0)

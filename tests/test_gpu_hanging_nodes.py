@@ -24,14 +24,13 @@ def _defaults(gpu_ctx):
     for k in range(8):
         gpu_ctx.set_solid(k, np.zeros((0, 12)))
     for name, v in (("tile", 3), ("integration", 0), ("lds_stage", 2), ("stage_slots", 0), ("algorithm", 0),
-                    ("xcd_mode", 2), ("precision", 0), ("entry_key", 1)):
+                    ("xcd_mode", 2), ("entry_key", 1)):
         gpu_ctx.set_option(name, v)
     gpu_ctx.set_row_tiles(0, 0, 1)
     gpu_ctx.set_row_range(0, -1)
     gpu_ctx.set_alpha_limit(2.5)
     yield
     gpu_ctx.set_option("entry_key", 1)
-    gpu_ctx.set_option("precision", 0)
 
 
 def _frame(ctx, rots, rx, ry):
@@ -65,7 +64,10 @@ def test_coarse_box_against_a_refined_one(gpu_ctx, oracle_port, warp, weld):
 
 def test_the_fixture_bites_without_the_depth_key(gpu_ctx, oracle_port):
     """"entry_key" 0 = entries keyed at their face's own depth, strict comparison (rounds 1-2): whether the abutting
-    cell is found is then a coin toss per crossing, and rays are cut short.  Keeps the fixtures honest."""
+    cell is found is then a coin toss per crossing, and rays were cut short with status C5_OK.  Since round 4 the walk
+    notices: the abutting entry it could not take lies a rounding error BEFORE the depth at which the ray left the grid,
+    i.e. inside the stretch the ray had walked - such rays are counted, the library answers C5_RETRY and renders the
+    frame with bin_sort_resolve.  Either way the walk alone did not deliver the frame.  Keeps the fixtures honest."""
     xyz, cells, _ = mg.refined_interface(4, 2, 4, jitter=0.12, warp=0.1, seed=11)
     alpha, q = mg.scalars(len(cells), seed=12)
     gpu_ctx.upload_grid(xyz, cells, alpha, q)
@@ -77,9 +79,9 @@ def test_the_fixture_bites_without_the_depth_key(gpu_ctx, oracle_port):
         _, st0 = _frame(gpu_ctx, rots, 260, 190)
         gpu_ctx.set_option("entry_key", 1)
         _, st1 = _frame(gpu_ctx, rots, 260, 190)
-        assert st1["segments"] == ref["segments"]
+        assert st1["segments"] == ref["segments"] and st1["steps"] > 0  # (setting "entry_key" lets the walk try again)
         assert st0["segments"] <= ref["segments"]
-        lost += ref["segments"] - st0["segments"]
+        lost += (ref["segments"] - st0["segments"]) + int(st0["steps"] == 0)  # rays cut short, or the frame redone without a walk
     assert lost > 0, "no ray was lost with the old keying: the fixture does not exercise the interface"
 
 
@@ -108,7 +110,7 @@ def test_single_hanging_nodes(gpu_ctx, oracle_port, seed):
             assert_images_match(img, ref["image"], f"seed {seed} view {view} order {order}")
 
 
-def test_refined_interface_mixed_precision_and_shards(gpu_ctx, oracle_port):
+def test_refined_interface_orders_and_shards(gpu_ctx, oracle_port):
     xyz, cells, _ = mg.refined_interface(5, 2, 3, jitter=0.1, warp=0.06, seed=21)
     alpha, q = mg.scalars(len(cells), seed=22)
     gpu_ctx.upload_grid(xyz, cells, alpha, q)
@@ -119,14 +121,11 @@ def test_refined_interface_mixed_precision_and_shards(gpu_ctx, oracle_port):
         full, st = _frame(gpu_ctx, rots, rx, ry)
         assert st["segments"] == ref["segments"]
         assert_images_match(full, ref["image"], f"view {view}")
-        # "precision" 1: same bar for the image, the count may differ by grazing rays
-        gpu_ctx.set_option("precision", 1)
-        for order in (0, 1):
-            gpu_ctx.set_option("integration", order)
-            img, stm = _frame(gpu_ctx, rots, rx, ry)
-            assert_images_match(img, ref["image"], f"mixed view {view} order {order}")
-            assert abs(stm["segments"] - ref["segments"]) <= max(3, ref["segments"] // 5000)
-        gpu_ctx.set_option("precision", 0)
+        # front to back: the same cells in the other order
+        gpu_ctx.set_option("integration", 1)
+        img, st1 = _frame(gpu_ctx, rots, rx, ry)
+        assert_images_match(img, ref["image"], f"front to back, view {view}")
+        assert st1["segments"] == ref["segments"]
         gpu_ctx.set_option("integration", 0)
         # sharded like the ranks of a multi-GPU run: cyclic tiles and blocks reassemble to the same bits
         strips = []
@@ -154,8 +153,8 @@ def test_refined_interface_at_scale(gpu_ctx, oracle_port):
 @pytest.mark.parametrize("view", [(0.1, 0.07), (0.37, -0.61)], ids=["bench-view", "oblique"])
 def test_refined_interface_at_the_benchmark_size(gpu_ctx, oracle_port, view):
     """BASELINE's own scale: 98 304 coarse + 786 432 fine cells (884 736; 2 048 coarse interface faces against
-    8 192 fine ones) at 2400x1800 — every pixel of the frame, S and covered against the CPU oracle, in the fp64 walk
-    (both orders) and the mixed walk, plus an 8-way cyclic split reassembled bit for bit.  In the bench view the
+    8 192 fine ones) at 2400x1800 — every pixel of the frame, S and covered against the CPU oracle, in both
+    integration orders, plus an 8-way cyclic split reassembled bit for bit.  In the bench view the
     interface is seen at 13 degrees (5 % of the rays cross it), in the oblique one most rays do."""
     xyz, cells, n_coarse = mg.refined_interface(32, 16, 32, lo=(0.5, -0.5, -0.5), size=1.0, jitter=0.1, warp=0.05, seed=77)
     assert n_coarse == 98_304 and len(cells) == 884_736
@@ -173,11 +172,6 @@ def test_refined_interface_at_the_benchmark_size(gpu_ctx, oracle_port, view):
     assert st1["segments"] == ref["segments"]
     assert_images_match(img, ref["image"], "front to back")
     gpu_ctx.set_option("integration", 0)
-    gpu_ctx.set_option("precision", 1)
-    img, stm = _frame(gpu_ctx, rots, 2400, 1800)
-    gpu_ctx.set_option("precision", 0)
-    assert_images_match(img, ref["image"], "mixed walk")
-    assert abs(stm["segments"] - ref["segments"]) <= ref["segments"] // 5000
     strips = []
     for rank in range(8):
         gpu_ctx.set_row_tiles(16, rank, 8)

@@ -36,18 +36,16 @@ def test_two_ranks_reassemble_every_frame(layout, extra):
 
 
 def test_bench_two_ranks_reports_the_baseline_configs():
-    """`bench.py --gpus 2` as the driver launches it (here: gloo, both ranks on the one GPU, a small grid and small
-    images): the headline is the N = 1 frame split by rows (strong scaling) beside its own one-GPU time, followed by
+    """`python bench.py --gpus 2` started by ONE plain command (bench.py spawns its ranks itself, as
+    a child `torch.distributed.run` job, before it has touched the GPU; here: gloo, both ranks on the one GPU, a small
+    grid and small images): the headline is the N = 1 frame split by rows (strong scaling) beside its own one-GPU time, followed by
     BASELINE config 4 (a larger frame split by rows) and config 5 (a -D sweep with the solids, whole frames dealt to
     the ranks), each with the one-GPU time of the same work measured by rank 0 in the same run."""
     import json
-    import socket
     env = dict(os.environ, C5_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = str(sock.getsockname()[1])
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"),
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(v, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--steps", "6", "--warmup", "2", "--backend", "gloo", "--workload", "kuhn12",
                         "--res", "400x300", "--config4-res", "800x600", "--config5-frames", "8", "--no-native", "--no-steady"],
                        env=env, capture_output=True, text=True, timeout=900)
@@ -56,6 +54,7 @@ def test_bench_two_ranks_reports_the_baseline_configs():
     assert len(lines) == 1, r.stdout[-2000:]
     b = json.loads(lines[0])
     assert b["n_gpus"] == 2 and b["scaling"] == "strong" and b["steps"] == 6 and b["value"] > 0
+    assert b["rccl_ranks"] == 2 and sorted(r_["rank"] for r_ in b["ranks"]) == [0, 1] and len({r_["pid"] for r_ in b["ranks"]}) == 2
     assert "400x300" in b["metric"] and "STRONG" in b["metric"]
     assert b["one_gpu"]["ms_per_frame"] > 0 and b["speedup_vs_one_gpu"] > 0
     assert abs(b["speedup_vs_one_gpu"] - b["one_gpu"]["ms_per_frame"] / b["ms_per_step"]) < 0.01
