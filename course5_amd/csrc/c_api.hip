@@ -5,6 +5,7 @@
 
 #include <algorithm>
 
+#include <cfloat>
 #include <cmath>
 #include <cstdarg>
 #include <cstddef>
@@ -119,6 +120,13 @@ struct FrameSlot {
     bool setup_kept = false;      // ... and the walk that used them left the entry heads in place
     bool setup_reused = false;    // the last frame enqueued into this slot skipped the per-view setup
     const c5::FrameCounters* raster_counters = nullptr;  // device: counters of the frame whose raster built the slot's entry lists
+    // "depth_split" (device_types.hpp: SplitParams)
+    DeviceBuffer plane_cell, straddle, straddle_count, partials, arrivals;
+    int split_k = 0;             // slabs the buffers above are laid out for (0: none)
+    int64_t split_px = 0, split_tiles = 0, split_cells = 0;
+    uint64_t split_seq = 0;      // raster frames so far: stamp = seq % 15 + 1, counter half = seq & 1
+    int setup_split = 1;         // slabs the slot's per-view data (plane cells) were built for ("view_cache")
+    double setup_w[c5::kMaxSlabs + 1] = {};
     int64_t entry_capacity = 0;
     bool head_clean = false;  // the per-pixel entry heads are all zero (the walk kernels leave them so)
     c5::FrameCounters* host_counters = nullptr;  // pinned
@@ -154,6 +162,10 @@ struct c5_context {
     int view_cache = 1;     // "view_cache": a frame with the view of the two before it reuses their per-view data (enqueue_frame)
     uint64_t setup_epoch = 1;  // bumped by everything but the view, the alpha limit and the solids that the per-view data depend on
     int solid_interior_faces = 0;  // 1: interior faces are rastered too (they cover nothing the others do not; testing)
+    int depth_split = 0;    // "depth_split": 0 = chosen per frame (split_auto_k), 1 = never, 2..8 = that many slabs
+    int split_auto_k = 1;   // what the last finished frame suggests (finish_frame)
+    double box_lo[3] = {0, 0, 0}, box_hi[3] = {0, 0, 0};  // the grid's bounding box in object space
+    double alpha_floor = 0.0;  // smallest alpha of the grid that is >= DBL_EPSILON (+inf: none)
     int overlap_setup = 0;  // measured: 1.27 vs 1.26 ms/frame, the side stream buys nothing
     DeviceBuffer px, py, pz, cell_vert, cell_adj, alpha, q, bface;
     double alpha_top = 0.0;      // largest alpha of the grid (c5_upload_grid / c5_update_scalars)
@@ -270,6 +282,30 @@ int to_rotation_list(c5_context* ctx, const c5_rotation* rots, int n, c5::Rotati
     }
     return C5_OK;
 }
+
+// tetra.cpp:44-62 on the host (what rotate_point does on the device), for bounding boxes and centres
+void rotate_host(const c5::RotationList& R, double c[3]) {
+    for (int r = 0; r < R.n; ++r) {
+        const double co = R.cosv[r], si = R.sinv[r];
+        if (R.axis[r] == 0) {
+            const double y_old = c[1];
+            c[1] = c[1] * co - c[2] * si;
+            c[2] = y_old * si + c[2] * co;
+        } else {
+            c[0] -= R.x0[r];
+            const double x_old = c[0];
+            c[0] = c[0] * co - c[2] * si;
+            c[2] = x_old * si + c[2] * co;
+            c[0] += R.x0[r];
+        }
+    }
+}
+
+// "depth_split": below this clamped alpha (and above DBL_EPSILON, where a cell stops taking part: line.cpp:220-224) the
+// reference's recurrence I = (Q - (Q - alpha I) exp(-alpha dz)) / alpha is dominated by its own cancellation error
+// (eps Q / alpha per step: golden fixture g4), which depends on the very bits of the I it is fed: partial integrals
+// composed afterwards cannot reproduce it.  A grid with such a cell is walked whole unless the caller forces the split.
+constexpr double kSplitAlphaFloor = 1e-6;
 
 int recompute_rows(c5_context* ctx) {
     c5::ImageParams& im = ctx->im;
@@ -557,6 +593,66 @@ int enqueue_frame(c5_context* ctx, float2* out_dev, c5::FrameCounters* own_count
     fs.sb_key = sb_key;
     fs.sb_n = n_sb;
     const bool bin_sort = ctx->algorithm == 1 || !ctx->grid_conforming || ctx->overlap_seen;
+    // "depth_split" (device_types.hpp: SplitParams): how many slabs of depth this frame's rays are cut into
+    int split_k = 1;
+    double split_w[c5::kMaxSlabs + 1] = {};
+    {
+        const bool able = !bin_sort && !ctx->pipeline && !ctx->fuse_setup && !ctx->overlap_setup && ctx->order == 0 &&
+                          ctx->tile_shape == 3 && ctx->xcd_mode == 2 && ctx->lds_stage == 2 && g.n_cells > 0 &&
+                          g.n_cells < (int64_t{1} << 25) && im.n_local_rows > 0;
+        double a_floor = ctx->alpha_floor;  // the smallest clamped alpha >= DBL_EPSILON any cell can have
+        if (ctx->alpha_limit < a_floor) a_floor = ctx->alpha_limit >= DBL_EPSILON ? ctx->alpha_limit : INFINITY;
+        const bool well_conditioned = a_floor >= kSplitAlphaFloor;
+        int want = 1;
+        if (ctx->depth_split >= 2) want = ctx->depth_split;  // (forced: the caller answers for the conditioning)
+        else if (ctx->depth_split == 0 && well_conditioned) want = ctx->split_auto_k;
+        if (able && want > 1) {
+            // the grid's depth range under this view, from the corners of its bounding box; planes at equal distances
+            double z_lo = INFINITY, z_hi = -INFINITY;
+            for (int corner = 0; corner < 8; ++corner) {
+                double c[3] = {(corner & 1) ? ctx->box_hi[0] : ctx->box_lo[0], (corner & 2) ? ctx->box_hi[1] : ctx->box_lo[1],
+                               (corner & 4) ? ctx->box_hi[2] : ctx->box_lo[2]};
+                rotate_host(ctx->view, c);
+                z_lo = std::fmin(z_lo, c[2]);
+                z_hi = std::fmax(z_hi, c[2]);
+            }
+            if (z_hi > z_lo && std::isfinite(z_hi - z_lo)) {
+                split_k = std::min(want, c5::kMaxSlabs);
+                split_w[0] = -DBL_MAX;
+                split_w[split_k] = DBL_MAX;
+                // (a hair off the k / K-th: structured grids have whole layers of nodes - and faces - at simple fractions of
+                // their depth range, and a face lying IN a cutting plane to rounding makes which of its two cells starts the
+                // job above a coin toss per pixel: harmless for the image, but the cell below is then counted by nobody)
+                for (int k = 1; k < split_k; ++k) split_w[k] = z_lo + (z_hi - z_lo) * ((static_cast<double>(k) + 0.0309016994) / split_k);
+            }
+        }
+    }
+    if (split_k > 1) {
+        const int64_t tiles = c5::walk_tiles(im);
+        if (fs.split_k != split_k || fs.split_px != padded || fs.split_tiles != tiles || fs.split_cells != g.n_cells) {
+            // (re)lay out: plane cells [K - 1][pixels], the sharded list of cells that straddle a plane (room for every
+            // cell at every plane: a shard can never overflow), two halves of shard counters (build_records fills one while
+            // the other, cleared by the plane raster of the frame before, waits for the next frame), partial results
+            // [K][tiles * 64] x (tau, tauc, b: fp64; segments: u32), arrivals [tiles]
+            const int64_t waves = (g.n_cells + 63) / 64;
+            const int64_t cap = ((waves + c5::kStraddleShards - 1) / c5::kStraddleShards) * 64 * (split_k - 1);
+            C5_HIP(ctx, hipStreamSynchronize(s));
+            C5_HIP(ctx, fs.plane_cell.ensure(static_cast<size_t>(split_k - 1) * padded * sizeof(uint32_t)));
+            C5_HIP(ctx, fs.straddle.ensure(static_cast<size_t>(c5::kStraddleShards) * cap * sizeof(uint32_t)));
+            C5_HIP(ctx, fs.straddle_count.ensure(2 * c5::kStraddleShards * c5::kStraddleCounterStride * sizeof(uint32_t)));
+            C5_HIP(ctx, fs.partials.ensure(static_cast<size_t>(split_k) * tiles * 64 * 28));
+            C5_HIP(ctx, fs.arrivals.ensure(static_cast<size_t>(tiles) * sizeof(uint32_t)));
+            C5_HIP(ctx, hipMemsetAsync(fs.plane_cell.ptr, 0, fs.plane_cell.bytes, s));
+            C5_HIP(ctx, hipMemsetAsync(fs.straddle_count.ptr, 0, fs.straddle_count.bytes, s));
+            C5_HIP(ctx, hipMemsetAsync(fs.arrivals.ptr, 0, fs.arrivals.bytes, s));
+            fs.split_k = split_k;
+            fs.split_px = padded;
+            fs.split_tiles = tiles;
+            fs.split_cells = g.n_cells;
+            fs.split_seq = 0;
+            fs.setup_epoch = 0;  // whatever plane cells the slot held are gone
+        }
+    }
     // "view_cache" (the persistent device grid of a -D sweep: only the donor turns, main.cpp:112-116): transformed
     // vertices, records and entry lists depend on the grid, the image, the view, the alpha limit and the order - a frame
     // that has all of them in common with the frame before reuses them.  The walk normally hands the entry heads back
@@ -565,7 +661,8 @@ int enqueue_frame(c5_context* ctx, float2* out_dev, c5::FrameCounters* own_count
     // per-view setup.  A sweep whose view changes every frame never pays for any of this.
     const bool cacheable = ctx->view_cache && !ctx->pipeline && !bin_sort && !ctx->fuse_setup && !ctx->overlap_setup && g.n_cells > 0;
     const bool same_view = cacheable && fs.setup_epoch == ctx->setup_epoch && same_rotations(fs.setup_view, ctx->view) &&
-                           fs.setup_limit == ctx->alpha_limit && fs.setup_order == ctx->order;
+                           fs.setup_limit == ctx->alpha_limit && fs.setup_order == ctx->order && fs.setup_split == split_k &&
+                           std::memcmp(fs.setup_w, split_w, sizeof split_w) == 0;
     const bool reuse = same_view && fs.setup_kept;
     fs.setup_reused = reuse;
     fs.setup_epoch = cacheable ? ctx->setup_epoch : 0;
@@ -573,6 +670,36 @@ int enqueue_frame(c5_context* ctx, float2* out_dev, c5::FrameCounters* own_count
     fs.setup_limit = ctx->alpha_limit;
     fs.setup_order = ctx->order;
     fs.setup_kept = same_view;  // (this frame's walk leaves the heads in place)
+    fs.setup_split = split_k;
+    std::memcpy(fs.setup_w, split_w, sizeof split_w);
+    c5::SplitParams sp{};
+    if (split_k > 1) {
+        if (!reuse) {
+            fs.split_seq += 1;  // a new set of plane cells: a new stamp (the words of the 15 frames before it stay behind, invalid)
+            if (fs.split_seq % 15 == 0) C5_HIP(ctx, hipMemsetAsync(fs.plane_cell.ptr, 0, fs.plane_cell.bytes, s));  // stamps come round
+        }
+        const int64_t tiles = fs.split_tiles;
+        const int64_t waves = (g.n_cells + 63) / 64;
+        sp.n_slabs = split_k;
+        sp.stamp = static_cast<uint32_t>(fs.split_seq % 15) + 1u;
+        std::memcpy(sp.w, split_w, sizeof split_w);
+        sp.plane_cell = fs.plane_cell.as<uint32_t>();
+        sp.plane_stride = padded;
+        sp.straddle = fs.straddle.as<uint32_t>();
+        const size_t half = static_cast<size_t>(c5::kStraddleShards) * c5::kStraddleCounterStride;
+        sp.straddle_count = fs.straddle_count.as<uint32_t>() + (fs.split_seq & 1u) * half;
+        sp.straddle_count_next = fs.straddle_count.as<uint32_t>() + ((fs.split_seq + 1u) & 1u) * half;
+        sp.straddle_capacity = static_cast<uint32_t>(((waves + c5::kStraddleShards - 1) / c5::kStraddleShards) * 64 * (split_k - 1));
+        sp.part_stride = tiles * 64;
+        char* const base = static_cast<char*>(fs.partials.ptr);
+        const size_t n = static_cast<size_t>(split_k) * sp.part_stride;
+        sp.part_tau = reinterpret_cast<double*>(base);
+        sp.part_tauc = reinterpret_cast<double*>(base + n * 8);
+        sp.part_b = reinterpret_cast<double*>(base + n * 16);
+        sp.part_nseg = reinterpret_cast<uint32_t*>(base + n * 24);
+        sp.arrivals = fs.arrivals.as<uint32_t>();
+    }
+    g.split = sp;
     if (reuse) {
         c5::launch_clear_walk_counters(s, counters, sb, n_sb, fs.raster_counters);
     } else {
@@ -594,6 +721,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev, c5::FrameCounters* own_count
     if (!(ctx->fuse_setup && !side && g.n_cells > 0) && !reuse) {
         // (a cell's optics ride in its record since round 3 — one line per cell and step — and are rewritten with it)
         c5::launch_build_records(s, g, ctx->alpha_limit, ctx->order);
+        c5::launch_plane_raster(s, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im);  // ("depth_split"; nothing otherwise)
     }
     const bool fused = ctx->fuse_setup && !side && g.n_cells > 0;
     if (!fused) C5_HIP(ctx, mark(2, s));
@@ -658,6 +786,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev, c5::FrameCounters* own_count
         wp.small_exp_only = (a_max * ctx->edge_max < 0.125) ? 1 : 0;
     }
     wp.keep_entries = fs.setup_kept ? 1 : 0;
+    wp.split = sp;
     wp.row_cost = nullptr;
     wp.sb_cost = sb;
     wp.n_sb_rows = 0;
@@ -776,6 +905,20 @@ int finish_frame(c5_context* ctx) {
         ctx->rays_per_cell = static_cast<double>(hc.segments) * static_cast<double>(ctx->im.world > 0 ? ctx->im.world : 1) *
                              (static_cast<double>(ctx->im.res_y) / static_cast<double>(ctx->im.row_count > 0 ? ctx->im.row_count : ctx->im.res_y)) /
                              static_cast<double>(ctx->n_cells);
+    {   // "depth_split" 0: how many slabs the next frames' rays are cut into.  K jobs per tile of a K-th of a ray's steps each:
+        // worth it while the jobs do not fill the wavefront slots (a frame of one round lasts as long as ONE ray, however
+        // few rays it has) and the rays are long enough to be worth cutting.
+        int k = 1;
+        if (hc.covered > 0 && hc.segments > 0) {
+            const double jobs = 1.2 * static_cast<double>(hc.covered) / 64.0;  // tiles with rays (a fifth of them only partly covered)
+            const double slots = 256.0 * 4.0 * 7.0;                            // the split walk runs 7 wavefronts per SIMD
+            const double per_ray = static_cast<double>(hc.segments) / static_cast<double>(hc.covered);
+            k = static_cast<int>(std::lround(1.5 * slots / jobs));
+            k = std::min(k, static_cast<int>(per_ray / 24.0));
+            k = std::max(1, std::min(k, 4));
+        }
+        if (ctx->algorithm == 0 && ctx->grid_conforming && !ctx->overlap_seen) ctx->split_auto_k = k;
+    }
     st.covered_pixels = static_cast<int64_t>(hc.covered);
     st.solid_pixels = static_cast<int64_t>(hc.solid_pixels);
     st.entries = static_cast<int64_t>(hc.entries);
@@ -971,7 +1114,8 @@ void c5_destroy(c5_context* ctx) {
     for (DeviceBuffer* b : bufs) b->release();
     for (FrameSlot& fs : ctx->slots) {
         DeviceBuffer* sb[] = {&fs.vx, &fs.vy, &fs.vz, &fs.rec, &fs.count, &fs.head, &fs.first, &fs.pool,
-                              &fs.mask, &fs.counters, &fs.row_cost, &fs.sb};
+                              &fs.mask, &fs.counters, &fs.row_cost, &fs.sb, &fs.plane_cell, &fs.straddle, &fs.straddle_count,
+                              &fs.partials, &fs.arrivals};
         for (DeviceBuffer* b : sb) b->release();
         if (fs.host_counters) (void)hipHostFree(fs.host_counters);
         for (auto& ev : fs.ev)
@@ -1114,15 +1258,20 @@ int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int3
                 hi[k] = i ? std::fmax(hi[k], v) : v;
                 top = std::fmax(top, std::fabs(v));
             }
+        for (int k = 0; k < 3; ++k) ctx->box_lo[k] = lo[k], ctx->box_hi[k] = hi[k];
         ctx->grid_diagonal = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
         // (the view rotates about x = x0 of each rotation: a point's distance from that axis, hence its depth, stays
         // within the largest |coordinate| + |x0|; the constant below has room for both)
         ctx->coord_max = top + 2.0;
     }
     ctx->alpha_top = 0.0;
+    ctx->alpha_floor = INFINITY;
+    ctx->split_auto_k = 1;
     double edge2 = 0.0;
     for (int64_t c = 0; c < n_cells; ++c) {
         if (alpha[c] > ctx->alpha_top) ctx->alpha_top = alpha[c];  // (+inf counts: it is clamped to the limit; NaN never compares greater)
+        if (alpha[c] >= DBL_EPSILON && alpha[c] < ctx->alpha_floor) ctx->alpha_floor = alpha[c];
+        if (alpha[c] != alpha[c]) ctx->alpha_floor = 0.0;  // (a NaN alpha: no claim about conditioning)
         const int32_t* v = cell_vert + 4 * c;
         for (int a = 0; a < 4; ++a)
             for (int b = a + 1; b < 4; ++b) {
@@ -1154,8 +1303,12 @@ int c5_update_scalars(c5_context* ctx, const double* alpha, const double* q, int
         C5_HIP(ctx, hipMemcpy(ctx->q.ptr, q, static_cast<size_t>(n_cells) * 8, hipMemcpyHostToDevice));
     }
     ctx->alpha_top = 0.0;
-    for (int64_t i = 0; i < n_cells; ++i)
+    ctx->alpha_floor = INFINITY;
+    for (int64_t i = 0; i < n_cells; ++i) {
         if (alpha[i] > ctx->alpha_top) ctx->alpha_top = alpha[i];
+        if (alpha[i] >= DBL_EPSILON && alpha[i] < ctx->alpha_floor) ctx->alpha_floor = alpha[i];
+        if (alpha[i] != alpha[i]) ctx->alpha_floor = 0.0;
+    }
     return C5_OK;
 }
 
@@ -1404,6 +1557,10 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
         for (Solid& so : ctx->solids) so.own_mask_ready = false, so.unchanged_frames = 0, so.seen_generation = ~uint64_t{0};
     } else if (n == "view_cache") {
         ctx->view_cache = static_cast<int>(value) != 0;
+    } else if (n == "depth_split") {
+        if (value < 0 || value > c5::kMaxSlabs || value != std::floor(value))
+            return fail(ctx, C5_ERR_INVALID, "depth_split must be 0 (per frame), 1 (never) or 2..%d slabs", c5::kMaxSlabs);
+        ctx->depth_split = static_cast<int>(value);
     } else if (n == "solid_cache") {
         ctx->solid_cache = static_cast<int>(value) != 0;
         for (Solid& so : ctx->solids) so.own_mask_ready = false, so.unchanged_frames = 0, so.seen_generation = ~uint64_t{0};

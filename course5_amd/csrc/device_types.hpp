@@ -96,6 +96,37 @@ struct alignas(8) EntryHead {
     int32_t chain;
 };
 
+// --- "depth_split" (round 4): a ray cut at planes of constant depth ------------------------------------------------
+// A ray is a chain of ~170 dependent steps of ~1.1 us; a frame (or one GPU's share of a frame) with fewer rays than the
+// GPU has wavefront slots lasts as long as that chain whatever its size.  With n_slabs = K > 1 the depth range of the
+// grid is cut at K - 1 planes w[1] < ... < w[K - 1] of the walk coordinate and every 8x8 pixel tile becomes K jobs: job s
+// walks its rays from w[s] to w[s + 1] (job 0 from the boundary entries, the last one until the ray leaves the grid for
+// good) and leaves per pixel a PARTIAL result - tau_s, the clamped optical depth tauc_s, and b_s = the recurrence of
+// line.cpp:206-225 started from I = 0 - and the tile's last job to arrive composes them in depth order:
+//     tau = sum tau_s,   I <- exp(-tauc_s) * I + b_s   (s = 0 ... K - 1; the recurrence is affine in I).
+// Where a ray is at depth w[s] is found by plane_raster: the cells that straddle the plane (listed by build_records)
+// are scan-converted like boundary faces, plane_cell[s - 1][pixel] = stamp << 28 | cell.
+constexpr int kMaxSlabs = 8;
+constexpr int kStraddleShards = 64;
+constexpr int kStraddleCounterStride = 32;  // u32 words: one 128-byte line per counter
+struct SplitParams {
+    int32_t n_slabs;            // K; 0 / 1: rays are walked whole
+    uint32_t stamp;             // 1..15: a plane_cell word is valid iff its bits 28-31 hold this (no clearing per frame)
+    double w[kMaxSlabs + 1];    // w[0] = -DBL_MAX, w[K] = +DBL_MAX
+    uint32_t* plane_cell;       // [K - 1][plane_stride]
+    int64_t plane_stride;       // pixels of the local image, padded
+    uint32_t* straddle;         // kStraddleShards lists of (cell | (plane - 1) << 28), appended to by build_records
+    uint32_t* straddle_count;   // [shard * kStraddleCounterStride] items in the shard's list: the half build_records fills this frame
+    uint32_t* straddle_count_next;  // the other half: zeroed by this frame's plane_raster for the next frame
+    uint32_t straddle_capacity; // per shard: 64 (K - 1) x the wavefronts of build_records that belong to it
+    double* part_tau;           // [K][part_stride] partial results, indexed tile * 64 + lane
+    double* part_tauc;
+    double* part_b;
+    uint32_t* part_nseg;        // segments counted by the job (+ flag bits 30, 31)
+    uint32_t* arrivals;         // [tiles] jobs of the tile that have delivered their partials (the last one composes, and zeroes it)
+    int64_t part_stride;        // tiles * 64
+};
+
 constexpr int kMaxRotations = 8;
 struct RotationList {
     int32_t n;

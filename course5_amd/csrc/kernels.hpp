@@ -21,6 +21,7 @@ struct GridView {  // device pointers of the persistent grid + per-view buffers
     ExitRecord* xrec = nullptr;  // fp64 walk: one 128-byte line per cell and view (exit candidates + optics)
     // only cells whose projected y-extent meets [cull_y_lo, cull_y_hi] can be reached by a ray of this context
     double cull_y_lo = 0, cull_y_hi = 0;
+    SplitParams split{};  // "depth_split": build_records lists the cells that straddle a cutting plane (n_slabs > 1)
 };
 
 struct WalkParams {
@@ -61,6 +62,7 @@ struct WalkParams {
     // 1: the walk leaves the per-pixel entry heads as they are (it normally hands them back cleared): the next frame has
     // the same view and reuses the entry lists, the records and the transformed vertices (c_api.hip: "view_cache")
     int32_t keep_entries;
+    SplitParams split;          // "depth_split" (device_types.hpp); n_slabs <= 1: whole rays
     unsigned* sticky;           // [0] entries without a pool slot, [1] rays over the step bound, [2] rays that skipped an entry
                                 // (interpenetrating components), summed over the frames since the host last looked; reset by the host only
 };
@@ -113,5 +115,9 @@ void launch_setup_fused(hipStream_t s, const GridView& g, double alpha_limit, in
                         const ImageParams& im, EntryHead* head, Entry* first, Entry* pool, int64_t capacity,
                         FrameCounters* counters, unsigned* sticky, int want_upper, double key_slack);
 void launch_walk(hipStream_t s, const WalkParams& p, int tile_shape);
+// "depth_split": the cells build_records listed as straddling a cutting plane, scan-converted into split.plane_cell
+void launch_plane_raster(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab, const ImageParams& im);
+// pixels x, y tiles of the walk's 8x8 tiling (what SplitParams::arrivals / part_* are sized by)
+int64_t walk_tiles(const ImageParams& im);
 
 }  // namespace c5

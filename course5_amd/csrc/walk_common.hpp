@@ -328,30 +328,38 @@ __device__ __forceinline__ EntryHead load_entry_head(const EntryHead* p) {
 // Interpenetrating components (round 4).  Two parts of a grid that share no face but overlap in space — the reference bins
 // and sorts any soup (plane.cpp:184-192, line.cpp:138) — cannot be walked: inside the overlap a ray is in two cells at
 // once.  Connectivity does not show it, but the entry lists do: such a ray meets a boundary entry INSIDE a stretch it
-// has just walked through cells (between the key of the entry it took last, w_taken, and where it left the grid, w_cur),
-// an entry it can never take.  `skipped` is set for it (a margin of two slacks either side keeps the twin entries of a
-// pixel centre exactly on the common edge of two boundary faces, and the abutting entry of a hanging-node interface,
-// out of it); the walk counts such rays, and the host answers with C5_RETRY and renders the grid with bin_sort_resolve
-// from then on (c_api.hip: finish_frame).  Only on the (re-)entry path: nothing is added to a step.
+// has just walked through cells — beyond the entry it took last (key_taken: that entry's key; -DBL_MAX for a ray that
+// started from a cutting plane), before the depth at which it left the grid (stretch_hi) — an entry it can never take.
+// `skipped` is set for it, with a margin of twice the entry's own key slack either side (keeps out the twin entries of
+// a pixel centre exactly on the common edge of two boundary faces, and the abutting entry of a hanging-node interface,
+// whose depth is that of the exit to rounding); the walk counts such rays, and the host answers with C5_RETRY and
+// renders the grid with bin_sort_resolve from then on (c_api.hip: finish_frame).  Only on the (re-)entry path: nothing
+// is added to a step.
+//
+// "depth_split": a job owns the entries whose own depth lies in [own_lo, own_hi) — below own_lo by no more than the
+// entry's key slack: an abutting entry across a cutting plane may evaluate a rounding error below it — so that the
+// jobs of a ray take every entry once (device_types.hpp: SplitParams; whole rays: -DBL_MAX, DBL_MAX); entries below
+// own_lo belong to the stretch of a job further down and are not judged here.
 template <bool kUp>
 __device__ __forceinline__ int next_entry(const WalkParams& P, size_t lp, EntryHead h, double& w_cur, double& w_entry,
-                                          double w_taken, bool& skipped) {
+                                          double key_taken, double stretch_hi, bool& skipped, double own_lo = -DBL_MAX,
+                                          double own_hi = DBL_MAX) {
     double key_best = DBL_MAX;
     int cell = -1;
-    const double margin = 2.0 * P.key_slack;
     const Entry* e = P.entry_first + lp;
     int hop = h.chain;
     for (int k = 0; k < h.count; ++k) {  // bounded by the count: a chain cut short by a pool overflow ends at hop 0
         const double z = e->z;
         const uint32_t word = e->cell;
         const double we = kUp ? z : -z;
-        const double key = we + ldexp(P.key_slack, static_cast<int>(word >> kEntrySlackShift));
-        if (key > w_cur && key < key_best) {
+        const double slack = ldexp(P.key_slack, static_cast<int>(word >> kEntrySlackShift));
+        const double key = we + slack;
+        if (key > w_cur && key < key_best && we < own_hi && key >= own_lo) {
             key_best = key;
             cell = static_cast<int>(word & kIdMask);
             w_entry = we;
         }
-        if (key > w_taken + margin && key < w_cur - margin) skipped = true;
+        if (key > key_taken + 2.0 * slack && we + 2.0 * slack < stretch_hi && we > own_lo) skipped = true;
         if (hop <= 0 || hop > P.pool_capacity) break;
         e = P.entry_pool + (hop - 1);
         hop = e->next;

@@ -35,6 +35,11 @@ struct alignas(16) Q4 {
 };
 constexpr int kRecPad = 9;  // 16-byte units per record in LDS: 8 + 1 pad (conflict-free b128 rows)
 
+// How far beyond a cutting plane a cell may begin and still be listed for it / claim a pixel of it (plane_raster): the
+// rounding of a point-in-cell test, generously — a claim this far off moves the start of one chord by as much.
+__device__ __forceinline__ double plane_tolerance(double coord, double extent) { return 64.0 * DBL_EPSILON * (coord + extent); }
+
+template <bool SPLIT>
 __device__ __forceinline__ void build_records_block(const GridView& g, double alpha_limit, int order, unsigned block,
                                                     Q4 (*s_rec)[64 * kRecPad]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -43,9 +48,40 @@ __device__ __forceinline__ void build_records_block(const GridView& g, double al
     bool valid = cell < g.n_cells;
     CellRecord r;
     CellOptics o;
-    if (valid) valid = build_cell_impl<true>(g, alpha_limit, order, cell, r, o, nullptr);
+    double verts[4][3];
+    if (valid) valid = build_cell_impl<true>(g, alpha_limit, order, cell, r, o, SPLIT ? verts : nullptr);
     const unsigned long long valid_mask = __builtin_amdgcn_ballot_w64(valid);
     if (valid_mask == 0ull) return;  // wave-uniform
+    if (SPLIT) {
+        // "depth_split": the cells that straddle a cutting plane go on the list plane_raster works through (one
+        // allocation per wavefront and plane; the list has room for every cell at every plane)
+        double z_lo = 0.0, z_hi = 0.0, tol = 0.0;
+        if (valid) {
+            z_lo = fmin(fmin(verts[0][2], verts[1][2]), fmin(verts[2][2], verts[3][2]));
+            z_hi = fmax(fmax(verts[0][2], verts[1][2]), fmax(verts[2][2], verts[3][2]));
+            double coord = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) coord = fmax(coord, fmax(fabs(verts[k][0]), fmax(fabs(verts[k][1]), fabs(verts[k][2]))));
+            tol = plane_tolerance(coord, z_hi - z_lo);
+        }
+        // The list is cut into kStraddleShards parts, each with its counter on a line of its own (thousands of wavefronts
+        // adding to ONE word would serialise at ~10 ns each); a wavefront belongs to the part (its index mod 64), and a
+        // part has room for everything its wavefronts could ever list (64 cells x (K - 1) planes each): no overflow.
+        const unsigned shard = static_cast<unsigned>((wave_first >> 6) % kStraddleShards);
+        for (int pl = 1; pl < g.split.n_slabs; ++pl) {
+            const double w = g.split.w[pl];
+            const bool cut = valid && z_lo <= w + tol && z_hi >= w - tol;
+            const unsigned long long cut_mask = __builtin_amdgcn_ballot_w64(cut);
+            if (cut_mask == 0ull) continue;
+            const int leader = __builtin_ctzll(cut_mask);
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(g.split.straddle_count + shard * kStraddleCounterStride, static_cast<unsigned>(__popcll(cut_mask)));
+            base = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(base), leader));
+            const unsigned at = base + static_cast<unsigned>(__popcll(cut_mask & ((1ull << lane) - 1ull)));
+            if (cut && at < g.split.straddle_capacity)
+                g.split.straddle[static_cast<size_t>(shard) * g.split.straddle_capacity + at] = static_cast<uint32_t>(cell) | (static_cast<uint32_t>(pl - 1) << 28);
+        }
+    }
     Q4* const my_rec = s_rec[wave];
     if (valid) {
         ExitRecord x;
@@ -63,9 +99,10 @@ __device__ __forceinline__ void build_records_block(const GridView& g, double al
     }
 }
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void build_records(GridView g, double alpha_limit, int order) {
     __shared__ Q4 s_rec[4][64 * kRecPad];
-    build_records_block(g, alpha_limit, order, blockIdx.x, s_rec);
+    build_records_block<SPLIT>(g, alpha_limit, order, blockIdx.x, s_rec);
 }
 
 __global__ __launch_bounds__(256) void entry_raster(GridView g, RasterArgs A) { entry_raster_block(g, A, blockIdx.x); }
@@ -82,13 +119,145 @@ __global__ __launch_bounds__(256) void setup_fused(GridView g, double alpha_limi
     if (raster)
         entry_raster_block(g, A, idx);
     else
-        build_records_block(g, alpha_limit, order, idx, s_rec);
+        build_records_block<false>(g, alpha_limit, order, idx, s_rec);
+}
+
+// ------------------------------------------------------------------------------------------
+// plane_raster ("depth_split"): where is every ray at the cutting planes?
+//
+// build_records has listed the cells that straddle a plane w = w[pl] (to a tolerance).  A wavefront takes one listed
+// cell: the plane cuts it in a triangle or a quadrilateral; the pixels of the cell's bounding box are tested against
+// the cell's four half-spaces at depth w, in NORMAL form — s_f(x, y) = n_f . (x, y, w) - d_f, oriented so that the
+// cell's fourth vertex is on the positive side: no division, vertical faces are faces like any other — and a pixel
+// inside gets plane_cell[pl - 1][pixel] = stamp << 28 | cell: the cell in which the job of slab pl starts that ray, at
+// depth w (walk_composite_lds<..., SPLIT>).  Two claims:
+//   * inside, every s_f >= 0: a plain store — cells that share the point (it lies on a common face) both contain it,
+//     whichever store lands last is right;
+//   * within the rounding of the test, every s_f >= -tol_f: taken only if nobody else has claimed the pixel (compare
+//     and swap against a word of another frame) — so that a point within rounding of a face never falls between the
+//     two cells that share it; such a start is off by the rounding of one plane evaluation.
+// A pixel no cell claims is outside the grid at that depth: its word keeps an old stamp, and the job looks for the
+// ray's next boundary entry instead.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void plane_raster(GridView g, const double* __restrict__ Xtab, const double* __restrict__ Ytab,
+                                                    ImageParams im) {
+    const int lane = threadIdx.x & 63;
+    const unsigned gw = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+    // the shards' fill counts -> one running sum across the lanes (lane k: items of shards 0 .. k)
+    unsigned incl = __hip_atomic_load(g.split.straddle_count + lane * kStraddleCounterStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    incl = incl < g.split.straddle_capacity ? incl : g.split.straddle_capacity;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned up = static_cast<unsigned>(__shfl_up(static_cast<int>(incl), d));
+        if (lane >= d) incl += up;
+    }
+    const unsigned total = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+    if (gw == 0) g.split.straddle_count_next[lane * kStraddleCounterStride] = 0u;  // (the half the NEXT frame's build_records fills)
+    for (unsigned item = gw; item < total; item += n_waves) {
+        const unsigned shard = static_cast<unsigned>(__popcll(__builtin_amdgcn_ballot_w64(incl <= item)));
+        const unsigned before = shard ? static_cast<unsigned>(__shfl(static_cast<int>(incl), static_cast<int>(shard) - 1)) : 0u;
+        const uint32_t word = g.split.straddle[static_cast<size_t>(shard) * g.split.straddle_capacity + (item - before)];
+        const uint32_t cell = word & kIdMask;
+        const int pl = static_cast<int>(word >> 28) + 1;
+        const double w = g.split.w[pl];
+        const int4 cv = g.cell_vert[cell];
+        const int vid[4] = {cv.x, cv.y, cv.z, cv.w};
+        double p[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            p[k][0] = g.vx[vid[k]];
+            p[k][1] = g.vy[vid[k]];
+            p[k][2] = g.vz[vid[k]];
+        }
+        // the four half-spaces at depth w: s_f(x, y) = fa x + fb y + fc >= 0 inside
+        constexpr int FV[4][4] = {{0, 1, 2, 3}, {0, 1, 3, 2}, {0, 2, 3, 1}, {1, 2, 3, 0}};
+        double fa[4], fb[4], fc[4], ft[4];
+        bool flat = false;
+        double coord = fabs(w);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) coord = fmax(coord, fmax(fabs(p[k][0]), fabs(p[k][1])));
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const double* a = p[FV[f][0]];
+            const double* b = p[FV[f][1]];
+            const double* c = p[FV[f][2]];
+            const double* o = p[FV[f][3]];
+            const double ux = b[0] - a[0], uy = b[1] - a[1], uz = b[2] - a[2];
+            const double vx = c[0] - a[0], vy = c[1] - a[1], vz = c[2] - a[2];
+            double nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+            const double side = nx * (o[0] - a[0]) + ny * (o[1] - a[1]) + nz * (o[2] - a[2]);
+            if (!(side != 0.0)) flat = true;  // (no volume, or NaN: claims nothing)
+            if (side < 0.0) nx = -nx, ny = -ny, nz = -nz;
+            fa[f] = nx;
+            fb[f] = ny;
+            fc[f] = nz * (w - a[2]) - nx * a[0] - ny * a[1];
+            // rounding of s_f at a pixel: a few ulps of the largest term
+            ft[f] = 32.0 * DBL_EPSILON * ((fabs(nx) + fabs(ny) + fabs(nz)) * coord);
+        }
+        if (flat) continue;
+        const double xmin = fmin(fmin(p[0][0], p[1][0]), fmin(p[2][0], p[3][0])), xmax = fmax(fmax(p[0][0], p[1][0]), fmax(p[2][0], p[3][0]));
+        const double ymin = fmin(fmin(p[0][1], p[1][1]), fmin(p[2][1], p[3][1])), ymax = fmax(fmax(p[0][1], p[1][1]), fmax(p[2][1], p[3][1]));
+        // conservative pixel box, as in entry_raster
+        const double fc0 = floor((xmin - im.x_min) / im.step_x), fc1 = ceil((xmax - im.x_min) / im.step_x);
+        const double fr0 = floor((ymin - im.y_min) / im.step_y), fr1 = ceil((ymax - im.y_min) / im.step_y);
+        if (!(fc1 >= 0.0) || !(fr1 >= 0.0) || !(fc0 <= im.res_x - 1.0) || !(fr0 <= im.res_y - 1.0)) continue;
+        const int c0 = static_cast<int>(fmax(fc0, 0.0));
+        const int c1 = static_cast<int>(fmin(fc1, im.res_x - 1.0));
+        const int r0 = max(static_cast<int>(fmax(fr0, 0.0)), im.row_begin);
+        const int r1 = min(static_cast<int>(fmin(fr1, im.res_y - 1.0)), im.row_begin + im.row_count - 1);
+        if (r1 < r0) continue;
+        int lr0, lr1;
+        local_row_span(im, r0, r1, lr0, lr1);
+        if (lr1 < lr0) continue;
+        const unsigned bw = static_cast<unsigned>(c1 - c0 + 1);
+        const unsigned n_box = bw * static_cast<unsigned>(lr1 - lr0 + 1);
+        uint32_t* const words = g.split.plane_cell + static_cast<size_t>(pl - 1) * g.split.plane_stride;
+        const uint32_t mine = (g.split.stamp << 28) | cell;
+        for (unsigned base = 0; base < n_box; base += 64u) {
+            const unsigned idx = base + static_cast<unsigned>(lane);
+            if (idx >= n_box) continue;
+            const unsigned qrow = idx / bw, rcol = idx - qrow * bw;
+            const int lrow = lr0 + static_cast<int>(qrow);
+            const int col = c0 + static_cast<int>(rcol);
+            const double x = Xtab[col], y = Ytab[global_row_of(im, lrow)];
+            bool inside = true, near = true;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const double sf = fma(fa[f], x, fma(fb[f], y, fc[f]));
+                inside = inside && sf >= 0.0;
+                near = near && sf >= -ft[f];
+            }
+            uint32_t* const at = words + static_cast<size_t>(lrow) * im.res_x + col;
+            if (inside) {
+                *at = mine;
+            } else if (near) {
+                const uint32_t old = __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((old >> 28) != g.split.stamp) atomicCAS(at, old, mine);
+            }
+        }
+    }
+}
+
+void launch_plane_raster(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab, const ImageParams& im) {
+    if (g.split.n_slabs <= 1 || g.n_cells <= 0) return;
+    // resident wavefronts share the listed cells between them (the list's length is on the device only)
+    long long blocks = (g.n_cells + 255) / 256;
+    blocks = blocks < 8 ? 8 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(plane_raster, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, g, Xtab, Ytab, im);
+}
+
+int64_t walk_tiles(const ImageParams& im) {
+    const int64_t tiles_x = (im.res_x + 7) / 8, tiles_y = (im.n_local_rows + 7) / 8;
+    return tiles_x * tiles_y;
 }
 
 void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, int order) {
     if (g.n_cells <= 0) return;
     const unsigned blocks = static_cast<unsigned>((g.n_cells + 255) / 256);
-    hipLaunchKernelGGL(build_records, dim3(blocks), dim3(256), 0, s, g, alpha_limit, order);
+    if (g.split.n_slabs > 1)
+        hipLaunchKernelGGL(build_records<true>, dim3(blocks), dim3(256), 0, s, g, alpha_limit, order);
+    else
+        hipLaunchKernelGGL(build_records<false>, dim3(blocks), dim3(256), 0, s, g, alpha_limit, order);
 }
 
 void launch_entry_lists(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
@@ -224,8 +393,8 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
     const bool in_image = (col < im.res_x) && (lrow < im.n_local_rows);
 
     unsigned n_seg = 0, n_step = 0, is_solid = 0, overflow = 0;
-    bool skipped = false;       // the ray met an entry inside a stretch it had walked (next_entry): interpenetrating components
-    double w_taken = -DBL_MAX;  // key of the entry the ray took last
+    bool skipped = false;        // the ray met an entry inside a stretch it had walked (next_entry): interpenetrating components
+    double key_taken = -DBL_MAX; // key of the entry the ray took last
     double tau = 0.0, I = 0.0, T = 1.0;
     double x = 0.0, y = 0.0, w_cur = -DBL_MAX, carry = 0.0;  // carry: the depth (walk coordinate) at which the ray entered the current cell
     EntryHead ent{0, 0};
@@ -249,8 +418,8 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
             y = P.Ytab[global_row_of(im, lrow)];
             // touched once per frame: keep them from displacing the cell records in L2 / Infinity Cache
             ent = load_entry_head(P.entry_head + lp);
-            if (ent.count > 0) cell = next_entry<kUp>(P, lp, ent, w_cur, carry, w_taken, skipped);
-            w_taken = w_cur;
+            if (ent.count > 0) cell = next_entry<kUp>(P, lp, ent, w_cur, carry, -DBL_MAX, -DBL_MAX, skipped);
+            key_taken = w_cur;
         }
     }
 
@@ -277,8 +446,9 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
             overflow = 1;
             nb = -1;
         } else if (nb < 0 && !overflow) {
-            nb = next_entry<kUp>(P, lp, ent, w_cur, carry_next, w_taken, skipped);  // left the grid: re-entry of a non-convex grid?
-            w_taken = w_cur;
+            // left the grid: re-entry of a non-convex grid?
+            nb = next_entry<kUp>(P, lp, ent, w_cur, carry_next, key_taken, has_exit ? sg.w_exit : -DBL_MAX, skipped);
+            key_taken = w_cur;
         }
 
         // issue the next cell's loads now; the arithmetic below does not depend on them
@@ -445,8 +615,12 @@ using LdsInts = const __attribute__((address_space(3))) int*;
 // pixels are coarse against the cells: more distinct cells per 8x8 tile — the host picks by the rays per cell of the
 // frame before (c_api.hip).
 // SMALLEXP: every exp argument of the frame lies in (-1/8, 0] (WalkParams::small_exp_only): only the short series.
-template <int TILE, int ORDER, bool DMA = false, int SLOTS = kStageSlots, bool SMALLEXP = false>
-__global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WALK_WAVES) void walk_composite_lds(WalkParams P) {
+// SPLIT ("depth_split", device_types.hpp: SplitParams): every tile is walked by P.split.n_slabs jobs, one per slab of
+// depth; a job leaves partial results and the tile's last job to arrive composes them.  ORDER 0, one wavefront per
+// workgroup.  Everything it adds is compiled out of the whole-ray instantiations.
+template <int TILE, int ORDER, bool DMA = false, int SLOTS = kStageSlots, bool SMALLEXP = false, bool SPLIT = false>
+__global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVES) : C5_WALK_WAVES) void walk_composite_lds(WalkParams P) {
+    static_assert(!SPLIT || (ORDER == 0 && DMA && TileShape<TILE>::GX * TileShape<TILE>::GY == 1), "depth_split: reference order, LDS-DMA, one wavefront per workgroup");
     constexpr int kStageSlots = SLOTS;  // (shadows the namespace constant: everything below is per instantiation)
     using TS = TileShape<TILE>;
     constexpr int TW = TS::WW * TS::GX, TH = TS::WH * TS::GY;
@@ -461,17 +635,31 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
     const ImageParams& im = P.im;
     const int tiles_x = (im.res_x + TW - 1) / TW;
     const int tiles_y = (im.n_local_rows + TH - 1) / TH;
+    // SPLIT: the K jobs of a tile follow one another on the same XCD (blocks b and b + 8 share one): block -> (tile block, slab)
+    int slab = 0;
+    unsigned bid = blockIdx.x;
+    if (SPLIT) {
+        const unsigned K = static_cast<unsigned>(P.split.n_slabs);
+        if (P.xcd_mode == 0) {
+            slab = static_cast<int>(bid % K);
+            bid = bid / K;
+        } else {
+            const unsigned seq_k = bid >> 3;
+            slab = static_cast<int>(seq_k % K);
+            bid = ((seq_k / K) << 3) | (bid & 7u);
+        }
+    }
     int tx, ty;
     if (P.xcd_mode == 0) {
-        ty = blockIdx.x / tiles_x;
-        tx = blockIdx.x - ty * tiles_x;
+        ty = bid / tiles_x;
+        tx = bid - ty * tiles_x;
     } else if (P.xcd_mode == 2) {
         // square super-blocks of S x S workgroups dealt round-robin to the 8 XCDs: the workgroups an XCD
         // runs at a time are neighbours in x AND y, so a cell's record is fetched into few L2s
         const int S = P.band_tiles;
         const int sbx_n = (tiles_x + S - 1) / S, sby_n = (tiles_y + S - 1) / S;
-        const int xcd = blockIdx.x & 7;
-        const int seq = blockIdx.x >> 3;
+        const int xcd = bid & 7;
+        const int seq = bid >> 3;
         const int sb = (seq / (S * S)) * 8 + xcd;
         const int within = seq - (seq / (S * S)) * (S * S);
         if (sb >= sbx_n * sby_n) return;
@@ -485,8 +673,8 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
         const int BAND = P.band_tiles;
         const int n_bands = (tiles_y + BAND - 1) / BAND;
         const int per_band = BAND * tiles_x;
-        const int xcd = blockIdx.x & 7;
-        const int seq = blockIdx.x >> 3;
+        const int xcd = bid & 7;
+        const int seq = bid >> 3;
         const int band = (seq / per_band) * 8 + xcd;
         const int within = seq - (seq / per_band) * per_band;
         if (band >= n_bands) return;
@@ -494,6 +682,9 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
         tx = within / BAND;
         if (ty >= tiles_y) return;
     }
+    // SPLIT: this job's slab of depth [w_lo, w_hi) (the first from -DBL_MAX, the last to +DBL_MAX)
+    const double w_lo = SPLIT ? P.split.w[slab] : -DBL_MAX;
+    const double w_hi = SPLIT ? P.split.w[slab + 1] : DBL_MAX;
 
     // Registers are what caps the resident wavefronts here, so per-lane state the steps do not need
     // (pixel index, entry head, solid colour, s_cur) is NOT carried through the loop: it is recomputed
@@ -517,6 +708,7 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
     unsigned n_seg = 0;
     unsigned n_step_wave = 0;  // wave-uniform: lane-steps taken by the whole wavefront
     double tau = 0.0, I = 0.0, T = 1.0;
+    double tauc = 0.0;  // SPLIT: sum of dz * clamped alpha over the job's cells: exp(-tauc) is what the job does to the I below it
     double x = 0.0, y = 0.0;
     double carry = 0.0;  // the depth (walk coordinate) at which the ray entered the cell it is about to cross
     int nb = -1;
@@ -535,7 +727,8 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
             ent = load_entry_head(P.entry_head + lp);
         }
         if (__builtin_amdgcn_ballot_w64(mv != 0u || ent.count != 0) == 0ull) {
-            if (in_image) {
+            // (SPLIT: every job of the tile comes to the same verdict; the first one writes the zeros)
+            if (in_image && slab == 0) {
                 __builtin_nontemporal_store(0.f, &P.out[lp].x);
                 __builtin_nontemporal_store(0.f, &P.out[lp].y);
             }
@@ -546,8 +739,16 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
             y = P.Ytab[global_row_of(im, pixel_lrow())];
             double w_cur = -DBL_MAX;
             bool skipped = false;
-            if (ent.count > 0) nb = next_entry<kUp>(P, lp, ent, w_cur, carry, -DBL_MAX, skipped);
-            my_scur[lane] = w_cur;
+            if (SPLIT && slab > 0) {
+                // where is the ray at the cutting plane?  (plane_raster; a word of another frame: nowhere inside the grid)
+                const uint32_t pc = P.split.plane_cell[static_cast<size_t>(slab - 1) * P.split.plane_stride + lp];
+                if ((pc >> 28) == P.split.stamp) {
+                    nb = static_cast<int>(pc & kIdMask);
+                    carry = w_lo;
+                }
+            }
+            if (nb < 0 && ent.count > 0) nb = next_entry<kUp>(P, lp, ent, w_cur, carry, -DBL_MAX, -DBL_MAX, skipped, w_lo, w_hi);
+            my_scur[lane] = w_cur;  // the key of the entry taken (-DBL_MAX: started from a plane)
         }
     }
     my_elect[kBuckets1 + 64 + lane] = 0;  // slot ids: always a valid cell id, whatever the slot's state
@@ -784,7 +985,10 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
             }
 
             const StepGeometry sg = step_geometry(cur, x, y);
-            const double dz = sg.w_exit - carry;  // line.cpp:124-131: the chord through the cell
+            // SPLIT: a cell that reaches beyond the job's slab is cut at the plane: the job ends there, and the job above takes
+            // the ray up from the plane (in this cell, if plane_raster found it there)
+            const bool clip = SPLIT && sg.w_exit >= w_hi && sg.w_exit < INFINITY;
+            const double dz = (clip ? w_hi : sg.w_exit) - carry;  // line.cpp:124-131: the chord through the cell
             const bool contributes = dz > 0.0 && dz < INFINITY;
             // (wave-uniform choice of the exp: every contributing lane's argument within (-1/8, 0] -> the short series;
             // C3 walk 0.4786 -> 0.4738 ms, at 4800x3600 1.614 -> 1.579.  Starting the next step's election — ticket
@@ -795,8 +999,10 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
             // read by the kernel, both paths kept, bought nothing: 0.4747 against 0.4741.)
             const bool short_exp = SMALLEXP || !kEmitNow || __builtin_amdgcn_ballot_w64(contributes && !(pend_o0.y * dz < -kSmallExpArg)) == 0ull;
             if (contributes) {
-                ++n_seg;
+                // (SPLIT: a cell is counted by the job in which the ray LEAVES it, so that a cell cut by a plane counts once)
+                if (!clip) ++n_seg;
                 tau = fma(dz, pend_o0.x, tau);  // line.cpp:189 (unclamped alpha); order-independent, done now
+                if (SPLIT) tauc = fma(dz, pend_o0.y, tauc);
                 if (kEmitNow) {
                     if (ORDER == 0) {
                         if (pend_o0.y != 0.0)  // line.cpp:220-224
@@ -818,13 +1024,16 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
             if (has_exit) carry = sg.w_exit;
             const uint32_t id = sg.w_out & kIdMask;
             int nxt = static_cast<int>(id);
-            if (id == kNoCell) {  // left the grid: re-entry of a non-convex grid?
+            if (id == kNoCell || clip) {  // left the grid: re-entry of a non-convex grid?  (or reached the end of the job's slab)
                 const size_t lp = pixel_index();
                 double w_cur = my_scur[lane];  // (the key of the entry the ray took last: only (re-)entries write it)
-                const double w_taken = w_cur;
+                const double key_taken = w_cur;
                 bool skipped = false;
                 if (has_exit) w_cur = fmax(w_cur, sg.w_exit);
-                nxt = next_entry<kUp>(P, lp, load_entry_head(P.entry_head + lp), w_cur, carry, w_taken, skipped);
+                // (a clipped ray takes no further entry - own_hi = -DBL_MAX owns none - but the entries inside the stretch it
+                // has walked, up to the plane, are judged all the same)
+                nxt = next_entry<kUp>(P, lp, load_entry_head(P.entry_head + lp), w_cur, carry, key_taken,
+                                      clip ? w_hi : (has_exit ? sg.w_exit : -DBL_MAX), skipped, w_lo, clip ? -DBL_MAX : w_hi);
                 if (skipped) n_seg |= kSkippedBit;
                 my_scur[lane] = w_cur;
             }
@@ -884,6 +1093,44 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
         }
     }
 
+    if (SPLIT) {
+        // The job's partial results, indexed tile * 64 + lane (whole 512-byte rows per array and wavefront), then the
+        // tile's arrival count: the job that finds K - 1 others already there composes the K partials in depth order and
+        // goes on to the common end (image, entry heads, statistics).  Release / acquire at agent scope around the count.
+        const unsigned K = static_cast<unsigned>(P.split.n_slabs);
+        const size_t tile = static_cast<size_t>(ty) * tiles_x + tx;
+        const size_t at = tile * 64u + static_cast<unsigned>(lane);
+        const size_t mine = static_cast<size_t>(slab) * P.split.part_stride + at;
+        P.split.part_tau[mine] = tau;
+        P.split.part_tauc[mine] = tauc;
+        P.split.part_b[mine] = I;
+        P.split.part_nseg[mine] = n_seg;
+        __threadfence();
+        unsigned before = 0;
+        if (lane == 0) before = atomicAdd(P.split.arrivals + tile, 1u);
+        before = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(before)));
+        if (before + 1u != K) {
+            if (lane == 0 && n_step_wave)
+                atomicAdd(&(P.counters + ((blockIdx.x * 4u + static_cast<unsigned>(wave)) % kCounterShards))->steps,
+                          static_cast<unsigned long long>(n_step_wave));
+            return;
+        }
+        __threadfence();
+        if (lane == 0) P.split.arrivals[tile] = 0u;  // (for the next frame; every job of this one has arrived)
+        tau = 0.0;
+        I = 0.0;
+        n_seg = 0u;
+        for (unsigned k = 0; k < K; ++k) {  // line.cpp:206-225 is affine in I: I <- exp(-tauc_k) I + b_k, from the back
+            const size_t from = static_cast<size_t>(k) * P.split.part_stride + at;
+            const double t_k = __hip_atomic_load(P.split.part_tau + from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double c_k = __hip_atomic_load(P.split.part_tauc + from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double b_k = __hip_atomic_load(P.split.part_b + from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned n_k = __hip_atomic_load(P.split.part_nseg + from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tau += t_k;
+            I = fma(exp_nonpositive(-c_k), I, b_k);
+            n_seg = (n_seg + (n_k & ~(kOverflowBit | kSkippedBit))) | (n_k & (kOverflowBit | kSkippedBit));
+        }
+    }
     const unsigned overflow = n_seg >> 31;
     const bool skipped = (n_seg & kSkippedBit) != 0u;
     n_seg &= ~(kOverflowBit | kSkippedBit);
@@ -997,6 +1244,18 @@ static void launch_walk_t(hipStream_t s, const WalkParams& p) {
         blocks = 8ll * ((n_sb + 7) / 8) * S * S;
         WalkParams q = p;
         q.band_tiles = S;
+        if constexpr (TILE == 3 && ORDER == 0) {
+            if (p.split.n_slabs > 1 && p.lds_stage == 2) {  // "depth_split": K jobs per tile (the host only asks for it in this configuration)
+                const unsigned grid = static_cast<unsigned>(blocks * p.split.n_slabs);
+                if (p.stage_slots > 14)
+                    hipLaunchKernelGGL((walk_composite_lds<3, 0, true, 21, false, true>), dim3(grid), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, q);
+                else if (p.small_exp_only)
+                    hipLaunchKernelGGL((walk_composite_lds<3, 0, true, kStageSlots, true, true>), dim3(grid), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, q);
+                else
+                    hipLaunchKernelGGL((walk_composite_lds<3, 0, true, kStageSlots, false, true>), dim3(grid), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, q);
+                return;
+            }
+        }
         if (p.lds_stage == 2 && p.stage_slots > 14)
             hipLaunchKernelGGL((walk_composite_lds<TILE, ORDER, true, 21>), dim3(static_cast<unsigned>(blocks)), dim3(kThreads), static_cast<size_t>(p.lds_pad), s, q);
         else if (launch_small_exp<TILE, ORDER>(s, q, blocks, kThreads))
