@@ -874,6 +874,7 @@ int finish_frame(c5_context* ctx) {
         hc.entry_overflow += p.entry_overflow;
         hc.odd_pixels += p.odd_pixels;
         hc.pool_used += p.pool_used;
+        hc.ray_tiles += p.ray_tiles;
     }
     c5_stats& st = ctx->last;
     // The order the next frames' rows of super-blocks start in.  A frame with fewer wavefronts of rays than about two
@@ -908,13 +909,16 @@ int finish_frame(c5_context* ctx) {
     {   // "depth_split" 0: how many slabs the next frames' rays are cut into.  K jobs per tile of a K-th of a ray's steps each:
         // worth it while the jobs do not fill the wavefront slots (a frame of one round lasts as long as ONE ray, however
         // few rays it has) and the rays are long enough to be worth cutting.
+        // Measured (profiles/r04_split_probe.md): K jobs per tile pay while K x (tiles with rays) still fit the slots in ONE
+        // round — the 124-row share of the C3 frame that one of 8 GPUs renders: walk 0.19 -> 0.13 (2 slabs); 4 slabs, 8 640
+        // jobs on 7 168 slots, are two rounds and no faster than 2 — and a slab is worth its plane raster and its jobs'
+        // start and end (~40 segments per ray and slab: the C2 ball's 70-segment rays are left whole).
         int k = 1;
-        if (hc.covered > 0 && hc.segments > 0) {
-            const double jobs = 1.2 * static_cast<double>(hc.covered) / 64.0;  // tiles with rays (a fifth of them only partly covered)
-            const double slots = 256.0 * 4.0 * 7.0;                            // the split walk runs 7 wavefronts per SIMD
+        if (hc.covered > 0 && hc.segments > 0 && hc.ray_tiles > 0) {
+            const double slots = 0.98 * 256.0 * 4.0 * 7.0;  // the split walk runs 7 wavefronts per SIMD
             const double per_ray = static_cast<double>(hc.segments) / static_cast<double>(hc.covered);
-            k = static_cast<int>(std::lround(1.5 * slots / jobs));
-            k = std::min(k, static_cast<int>(per_ray / 24.0));
+            k = static_cast<int>(slots / static_cast<double>(hc.ray_tiles));
+            k = std::min(k, static_cast<int>(per_ray / 40.0));
             k = std::max(1, std::min(k, 4));
         }
         if (ctx->algorithm == 0 && ctx->grid_conforming && !ctx->overlap_seen) ctx->split_auto_k = k;

@@ -170,6 +170,7 @@ struct alignas(128) FrameCounters {
                                   // components interpenetrate there (walk_common.hpp: next_entry) - not a grid a walk can render
     unsigned int odd_pixels;  // bin_sort_resolve: (pixel, cell) pairs with an odd number of covering faces
     unsigned int pool_used;   // per shard: slots asked of this shard's part of the overflow pool (may exceed the part)
+    unsigned int ray_tiles;   // wavefront tiles with at least one segment: the jobs a frame really has ("depth_split" 0 looks at it)
 };
 
 // global row -> local row of this rank, or -1

@@ -508,6 +508,7 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
         FrameCounters* const fc = P.counters + ((blockIdx.x * 4u + static_cast<unsigned>(threadIdx.x >> 6)) % kCounterShards);
         if (s_ent) atomicAdd(&fc->entries, static_cast<unsigned long long>(s_ent));
         if (s_seg) atomicAdd(&fc->segments, static_cast<unsigned long long>(s_seg));
+        if (s_seg) atomicAdd(&fc->ray_tiles, 1u);
         if (s_step) atomicAdd(&fc->steps, static_cast<unsigned long long>(s_step));
         if (s_cov) atomicAdd(&fc->covered, static_cast<unsigned long long>(s_cov));
         if (s_sol) atomicAdd(&fc->solid_pixels, static_cast<unsigned long long>(s_sol));
@@ -1096,16 +1097,20 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
     if (SPLIT) {
         // The job's partial results, indexed tile * 64 + lane (whole 512-byte rows per array and wavefront), then the
         // tile's arrival count: the job that finds K - 1 others already there composes the K partials in depth order and
-        // goes on to the common end (image, entry heads, statistics).  Release / acquire at agent scope around the count.
+        // goes on to the common end (image, entry heads, statistics).  The partials travel as RELAXED ATOMIC stores and
+        // loads at agent scope (write-through / read-through: coherent across the XCDs' L2s by themselves) with the
+        // wavefront's own vmcnt between its stores and its arrival — NOT as plain stores behind a release fence: an
+        // agent-scope release writes back the WHOLE L2 (buffer_wbl2), and 80 000 of those per launch made the first
+        // version of this kernel five times slower than the walk it replaces (profiles/r04_split_probe.md).
         const unsigned K = static_cast<unsigned>(P.split.n_slabs);
         const size_t tile = static_cast<size_t>(ty) * tiles_x + tx;
         const size_t at = tile * 64u + static_cast<unsigned>(lane);
         const size_t mine = static_cast<size_t>(slab) * P.split.part_stride + at;
-        P.split.part_tau[mine] = tau;
-        P.split.part_tauc[mine] = tauc;
-        P.split.part_b[mine] = I;
-        P.split.part_nseg[mine] = n_seg;
-        __threadfence();
+        __hip_atomic_store(P.split.part_tau + mine, tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(P.split.part_tauc + mine, tauc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(P.split.part_b + mine, I, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(P.split.part_nseg + mine, n_seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the four stores above have been performed
         unsigned before = 0;
         if (lane == 0) before = atomicAdd(P.split.arrivals + tile, 1u);
         before = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(before)));
@@ -1115,7 +1120,6 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
                           static_cast<unsigned long long>(n_step_wave));
             return;
         }
-        __threadfence();
         if (lane == 0) P.split.arrivals[tile] = 0u;  // (for the next frame; every job of this one has arrived)
         tau = 0.0;
         I = 0.0;
@@ -1179,6 +1183,7 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
         }
         if (s_ent) atomicAdd(&fc->entries, static_cast<unsigned long long>(s_ent));
         if (s_seg) atomicAdd(&fc->segments, static_cast<unsigned long long>(s_seg));
+        if (s_seg) atomicAdd(&fc->ray_tiles, 1u);
         if (n_step_wave) atomicAdd(&fc->steps, static_cast<unsigned long long>(n_step_wave));
         if (s_cov) atomicAdd(&fc->covered, static_cast<unsigned long long>(s_cov));
         if (s_sol) atomicAdd(&fc->solid_pixels, static_cast<unsigned long long>(s_sol));

@@ -16,7 +16,7 @@ from course5_amd import capi, meshgen as mg, sharding  # noqa: E402
 from course5_amd.build import kernel_source_hash  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 base = 6.0  # bench.py --row-base-cost
 ctx = capi.Context(0)
 ctx.set_option("view_cache", 0)  # a benchmark of identical frames: each one does its whole per-view setup

@@ -88,6 +88,7 @@ def main():
         from course5_amd import sharding
         rng = np.random.default_rng(seed + 77)
         ctx.set_option("lds_stage", 2); ctx.set_option("integration", 0); ctx.set_option("tile", 3)
+        ctx.set_option("depth_split", 1)  # (bit-equality across tilings: whole rays)
         ctx.set_row_tiles(0, 0, 1)
         ctx.set_row_range(0, -1)
         full = ctx.render()
@@ -106,6 +107,7 @@ def main():
             parts.append(ctx.render())
         ctx.set_row_range(0, -1)
         blk = np.concatenate(parts, axis=0)
+        ctx.set_option("depth_split", 0)
         for name, img2 in (("cyclic", cyc), ("blocks", blk)):
             if not np.array_equal(img2.view(np.uint32), full.view(np.uint32)):
                 bad += 1

@@ -25,7 +25,7 @@ def c3(gpu_ctx):
     xyz, cells, alpha, q = mg.workload("c3")
     for k in range(8):
         gpu_ctx.set_solid(k, np.zeros((0, 12)))
-    for name, v in (("tile", 3), ("integration", 0), ("lds_stage", 2), ("algorithm", 0), ("xcd_mode", 2)):
+    for name, v in (("tile", 3), ("integration", 0), ("lds_stage", 2), ("algorithm", 0), ("xcd_mode", 2), ("depth_split", 0)):
         gpu_ctx.set_option(name, v)
     gpu_ctx.set_row_range(0, -1)
     gpu_ctx.set_row_tiles(0, 0, 1)
@@ -52,6 +52,7 @@ def test_c4_row_tile_split_at_4800x3600(gpu_ctx, oracle_port, c3):
     xyz, cells, alpha, q = c3
     rots = mg.view_rotations(**mg.BENCH_VIEW)
     rx, ry, world, tile_rows = 4800, 3600, 8, 16
+    gpu_ctx.set_option("depth_split", 1)  # bit-equality across tilings: whole rays in every render
     gpu_ctx.set_image(rx, ry, mg.REFERENCE_BOUNDS)
     full = gpu_ctx.render()
     st_full = gpu_ctx.stats()

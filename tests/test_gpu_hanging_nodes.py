@@ -24,7 +24,7 @@ def _defaults(gpu_ctx):
     for k in range(8):
         gpu_ctx.set_solid(k, np.zeros((0, 12)))
     for name, v in (("tile", 3), ("integration", 0), ("lds_stage", 2), ("stage_slots", 0), ("algorithm", 0),
-                    ("xcd_mode", 2), ("entry_key", 1)):
+                    ("xcd_mode", 2), ("entry_key", 1), ("depth_split", 0)):
         gpu_ctx.set_option(name, v)
     gpu_ctx.set_row_tiles(0, 0, 1)
     gpu_ctx.set_row_range(0, -1)
@@ -118,6 +118,7 @@ def test_refined_interface_orders_and_shards(gpu_ctx, oracle_port):
     for view in VIEWS[:4]:
         rots = mg.view_rotations(*view)
         ref = oracle_port.render(xyz, cells, alpha, q, rots, rx, ry, mg.REFERENCE_BOUNDS, threads=8)
+        gpu_ctx.set_option("depth_split", 1)  # (the shards below must equal the full frame bit for bit)
         full, st = _frame(gpu_ctx, rots, rx, ry)
         assert st["segments"] == ref["segments"]
         assert_images_match(full, ref["image"], f"view {view}")
@@ -162,6 +163,7 @@ def test_refined_interface_at_the_benchmark_size(gpu_ctx, oracle_port, view):
     rots = mg.view_rotations(*view)
     gpu_ctx.upload_grid(xyz, cells, alpha, q)
     ref = oracle_port.render(xyz, cells, alpha, q, rots, 2400, 1800, mg.REFERENCE_BOUNDS, threads=16)
+    gpu_ctx.set_option("depth_split", 1)  # (the shards below must equal the full frame bit for bit: whole rays everywhere)
     full, st = _frame(gpu_ctx, rots, 2400, 1800)
     assert st["segments"] == ref["segments"] and st["covered_pixels"] == ref["covered"]
     assert st["entries"] > st["covered_pixels"] * (1.03 if view == (0.1, 0.07) else 1.4)  # rays that cross the interface enter twice

@@ -18,9 +18,14 @@ def _reset(gpu_ctx):
     gpu_ctx.set_option("view_cache", 1)
     gpu_ctx.set_option("stage_timing", 1)
     gpu_ctx.set_option("integration", 0)
+    # whole rays: these tests compare frames (and their step counts) across the moments at which "depth_split" 0 would
+    # begin to cut the rays of a small frame (the frame after the first statistics); tests/test_gpu_depth_split.py has the
+    # cache WITH the split
+    gpu_ctx.set_option("depth_split", 1)
     gpu_ctx.set_row_tiles(0, 0, 1)
     gpu_ctx.set_row_range(0, -1)
     yield
+    gpu_ctx.set_option("depth_split", 0)
     for k in range(8):
         gpu_ctx.set_solid(k, np.zeros((0, 12)))
     gpu_ctx.set_option("view_cache", 1)

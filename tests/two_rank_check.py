@@ -27,6 +27,7 @@ views = [mg.view_rotations(0.1 + 0.05 * k, 0.07 - 0.04 * k) for k in range(7)]
 ctx = capi.Context(0)
 if os.environ.get("C5_PIPELINE"):  # two frame slots inside the context as well
     ctx.set_option("pipeline", int(os.environ["C5_PIPELINE"]))
+ctx.set_option("depth_split", 1)  # the reassembled frames are compared bit for bit with single-context renders: whole rays
 ctx.upload_grid(xyz, cells, alpha, q)
 ctx.set_image(res_x, res_y, mg.REFERENCE_BOUNDS)
 stream = torch.cuda.Stream(device=dev)
@@ -72,6 +73,7 @@ with torch.cuda.stream(stream):
 ok = True
 if rank == 0:
     full = capi.Context(0)
+    full.set_option("depth_split", 1)
     full.upload_grid(xyz, cells, alpha, q)
     full.set_image(res_x, res_y, mg.REFERENCE_BOUNDS)
     from oracle.pyoracle import Oracle  # the checker: the reassembled frames also against the CPU oracle
