@@ -164,6 +164,8 @@ struct c5_context {
     int solid_interior_faces = 0;  // 1: interior faces are rastered too (they cover nothing the others do not; testing)
     int depth_split = 0;    // "depth_split": 0 = chosen per frame (split_auto_k), 1 = never, 2..8 = that many slabs
     int split_auto_k = 1;   // what the last finished frame suggests (finish_frame)
+    bool ray_depth_known = false;  // ... and the depths its rays ran between (walk coordinate)
+    double ray_depth_lo = 0.0, ray_depth_hi = 0.0;
     double box_lo[3] = {0, 0, 0}, box_hi[3] = {0, 0, 0};  // the grid's bounding box in object space
     double alpha_floor = 0.0;  // smallest alpha of the grid that is >= DBL_EPSILON (+inf: none)
     int overlap_setup = 0;  // measured: 1.27 vs 1.26 ms/frame, the side stream buys nothing
@@ -616,6 +618,11 @@ int enqueue_frame(c5_context* ctx, float2* out_dev, c5::FrameCounters* own_count
                 z_lo = std::fmin(z_lo, c[2]);
                 z_hi = std::fmax(z_hi, c[2]);
             }
+            // (the rays of the last finished frame ran between narrower bounds: rows of a frame, a view from a corner)
+            // (only when the library chooses the slabs itself: a forced count keeps planes that depend on the view alone, so
+            // that renders of different rows of one frame stay bit-equal)
+            if (ctx->depth_split == 0 && ctx->ray_depth_known && ctx->ray_depth_lo >= z_lo && ctx->ray_depth_hi <= z_hi)
+                z_lo = ctx->ray_depth_lo, z_hi = ctx->ray_depth_hi;
             if (z_hi > z_lo && std::isfinite(z_hi - z_lo)) {
                 split_k = std::min(want, c5::kMaxSlabs);
                 split_w[0] = -DBL_MAX;
@@ -875,6 +882,9 @@ int finish_frame(c5_context* ctx) {
         hc.odd_pixels += p.odd_pixels;
         hc.pool_used += p.pool_used;
         hc.ray_tiles += p.ray_tiles;
+        hc.seg_max = std::max(hc.seg_max, p.seg_max);
+        hc.exit_max_key = std::max(hc.exit_max_key, p.exit_max_key);
+        hc.entry_min_key = std::max(hc.entry_min_key, p.entry_min_key);
     }
     c5_stats& st = ctx->last;
     // The order the next frames' rows of super-blocks start in.  A frame with fewer wavefronts of rays than about two
@@ -913,13 +923,26 @@ int finish_frame(c5_context* ctx) {
         // round — the 124-row share of the C3 frame that one of 8 GPUs renders: walk 0.19 -> 0.13 (2 slabs); 4 slabs, 8 640
         // jobs on 7 168 slots, are two rounds and no faster than 2 — and a slab is worth its plane raster and its jobs'
         // start and end (~40 segments per ray and slab: the C2 ball's 70-segment rays are left whole).
+        // What a frame lasts is set by its LONGEST rays (seg_max), and they are cut evenly only if the planes divide THEIR
+        // depth range: the next frame's planes go between the shallowest entry and the deepest exit this frame's rays had
+        // (one GPU's rows of a frame see a part of the grid's depth range only; no earlier frame: the grid's bounding box).
         int k = 1;
         if (hc.covered > 0 && hc.segments > 0 && hc.ray_tiles > 0) {
+            // jobs that really walk: a tile's rays span about K x (their length / the longest ray's) slabs, + 1/2 for the
+            // plane they straddle; the other jobs of the tile find nothing to do and leave their slot at once
             const double slots = 0.98 * 256.0 * 4.0 * 7.0;  // the split walk runs 7 wavefronts per SIMD
-            const double per_ray = static_cast<double>(hc.segments) / static_cast<double>(hc.covered);
-            k = static_cast<int>(slots / static_cast<double>(hc.ray_tiles));
-            k = std::min(k, static_cast<int>(per_ray / 40.0));
-            k = std::max(1, std::min(k, 4));
+            const double mean_over_max = std::fmin(1.0, static_cast<double>(hc.segments) / static_cast<double>(hc.covered) / static_cast<double>(hc.seg_max ? hc.seg_max : 1u));
+            k = 1;
+            for (int t = 2; t <= 4; ++t)
+                if (static_cast<double>(hc.ray_tiles) * (t * mean_over_max + 0.5) <= slots) k = t;
+            k = std::min(k, static_cast<int>(static_cast<double>(hc.seg_max) / 56.0));
+            k = std::max(1, k);
+        }
+        ctx->ray_depth_known = hc.exit_max_key != 0 && hc.entry_min_key != 0;
+        if (ctx->ray_depth_known) {
+            ctx->ray_depth_lo = -c5::depth_of_key(hc.entry_min_key);
+            ctx->ray_depth_hi = c5::depth_of_key(hc.exit_max_key);
+            ctx->ray_depth_known = ctx->ray_depth_hi > ctx->ray_depth_lo;
         }
         if (ctx->algorithm == 0 && ctx->grid_conforming && !ctx->overlap_seen) ctx->split_auto_k = k;
     }
@@ -1271,6 +1294,7 @@ int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int3
     ctx->alpha_top = 0.0;
     ctx->alpha_floor = INFINITY;
     ctx->split_auto_k = 1;
+    ctx->ray_depth_known = false;
     double edge2 = 0.0;
     for (int64_t c = 0; c < n_cells; ++c) {
         if (alpha[c] > ctx->alpha_top) ctx->alpha_top = alpha[c];  // (+inf counts: it is clamped to the limit; NaN never compares greater)

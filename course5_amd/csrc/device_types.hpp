@@ -171,7 +171,23 @@ struct alignas(128) FrameCounters {
     unsigned int odd_pixels;  // bin_sort_resolve: (pixel, cell) pairs with an odd number of covering faces
     unsigned int pool_used;   // per shard: slots asked of this shard's part of the overflow pool (may exceed the part)
     unsigned int ray_tiles;   // wavefront tiles with at least one segment: the jobs a frame really has ("depth_split" 0 looks at it)
+    unsigned int seg_max;     // most segments of any ray of the frame (per job of a cut ray: of any part)
+    // the depths between which this frame's rays ran, as keys that atomicMax orders (0: no ray): depth_key() of the deepest
+    // exit, and of the NEGATED shallowest entry ("depth_split" 0 places the next frame's cutting planes between them)
+    unsigned long long exit_max_key;
+    unsigned long long entry_min_key;
 };
+// monotone map double -> u64, never 0 for a finite value (0 = "none" after the per-frame clear)
+__host__ __device__ inline unsigned long long depth_key(double w) {
+    union { double d; unsigned long long u; } v;
+    v.d = w;
+    return (v.u >> 63) ? ~v.u : (v.u | 0x8000000000000000ull);
+}
+__host__ __device__ inline double depth_of_key(unsigned long long k) {
+    union { double d; unsigned long long u; } v;
+    v.u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return v.d;
+}
 
 // global row -> local row of this rank, or -1
 __host__ __device__ inline int local_row_of(const ImageParams& im, int row) {

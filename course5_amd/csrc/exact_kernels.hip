@@ -527,6 +527,9 @@ __global__ __launch_bounds__(128) void clear_walk_counters(FrameCounters* __rest
         c.overlap_rays = 0;
         c.odd_pixels = 0;
         c.ray_tiles = 0;
+        c.seg_max = 0;
+        c.exit_max_key = 0;
+        c.entry_min_key = 0;
         if (raster_from) {
             c.entry_overflow = raster_from[i].entry_overflow;
             c.pool_used = raster_from[i].pool_used;

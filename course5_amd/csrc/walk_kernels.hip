@@ -585,6 +585,10 @@ __device__ unsigned long long g_walk_trace[4 * 131072];
             t_prev_ = t_now_;                                            \
         }                                                                \
     } while (0)
+#elif defined(C5_ISA_MARKERS)
+// scripts/walk_isa.py: the phase boundaries of the phase clock as comments in the assembly of the PRODUCT's kernel
+// (an empty asm statement: no instruction; the script checks that the loop's instruction count is the product's)
+#define C5_STAMP(k) asm volatile("; C5_PHASE_END " #k)
 #else
 #define C5_STAMP(k) \
     do {            \
@@ -611,6 +615,10 @@ __device__ unsigned long long g_walk_trace[4 * 131072];
 #ifndef C5_EMIT_NOW
 #define C5_EMIT_NOW 1
 #endif
+// 1: the scalar trims of round 4 in the loop of walk_composite_lds (profiles/r04_walk_isa.md); 0: the loop as it was (A/B builds)
+#ifndef C5_LOOP_TRIM
+#define C5_LOOP_TRIM 1
+#endif
 using LdsInts = const __attribute__((address_space(3))) int*;
 // SLOTS: distinct cells staged per wavefront and step: 14 (two DMA passes of seven), or 21 (three) for frames whose
 // pixels are coarse against the cells: more distinct cells per 8x8 tile — the host picks by the rays per cell of the
@@ -620,7 +628,7 @@ using LdsInts = const __attribute__((address_space(3))) int*;
 // depth; a job leaves partial results and the tile's last job to arrive composes them.  ORDER 0, one wavefront per
 // workgroup.  Everything it adds is compiled out of the whole-ray instantiations.
 template <int TILE, int ORDER, bool DMA = false, int SLOTS = kStageSlots, bool SMALLEXP = false, bool SPLIT = false>
-__global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVES) : C5_WALK_WAVES) void walk_composite_lds(WalkParams P) {
+__global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WALK_WAVES) void walk_composite_lds(WalkParams P) {
     static_assert(!SPLIT || (ORDER == 0 && DMA && TileShape<TILE>::GX * TileShape<TILE>::GY == 1), "depth_split: reference order, LDS-DMA, one wavefront per workgroup");
     constexpr int kStageSlots = SLOTS;  // (shadows the namespace constant: everything below is per instantiation)
     using TS = TileShape<TILE>;
@@ -695,6 +703,14 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
     auto pixel_col = [&]() { return tx * TW + (wave % TS::GX) * TS::WW + (lane % TS::WW); };
     auto pixel_lrow = [&]() { return ty * TH + (wave / TS::GX) * TS::WH + (lane / TS::WW); };
     auto pixel_index = [&]() { return static_cast<size_t>(pixel_lrow()) * im.res_x + pixel_col(); };
+    // the same from a lane index the compiler cannot trace back to `lane`: on the rare paths inside and behind the loop the
+    // pixel's index is then COMPUTED there (three instructions) instead of being hoisted in front of the loop and spilled
+    auto pixel_index_rare = [&]() {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int c = tx * TW + (wave % TS::GX) * TS::WW + (l % TS::WW), r = ty * TH + (wave / TS::GX) * TS::WH + (l / TS::WW);
+        return static_cast<size_t>(r) * im.res_x + c;
+    };
     const bool in_image = (pixel_col() < im.res_x) && (pixel_lrow() < im.n_local_rows);
     V2* const my_stage = s_stage[wave];
     int* const my_elect = s_elect[wave];
@@ -753,6 +769,14 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
         }
     }
     my_elect[kBuckets1 + 64 + lane] = 0;  // slot ids: always a valid cell id, whatever the slot's state
+    // (recomputed where it is wanted: nothing to keep in a register across the loop)
+    auto fc_job = [&]() { return P.counters + ((blockIdx.x * 4u + static_cast<unsigned>(wave)) % kCounterShards); };
+    {   // the shallowest depth at which a ray of this job starts (c_api.hip places the next frame's cutting planes by it)
+        double lo = nb >= 0 ? carry : DBL_MAX;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) lo = fmin(lo, __shfl_xor(lo, d));
+        if (lane == 0 && lo < DBL_MAX) atomicMax(&fc_job()->entry_min_key, depth_key(-lo));
+    }
 
     // contribution of the step whose record is being replaced (integrated while the next loads fly)
     // (optics kept as the two 16-byte halves they are read in: {alpha_raw, alpha_c}, {aux, q})
@@ -799,11 +823,15 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
     unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
     const unsigned long long t_begin_ = t_prev_;
 #endif
+    // (the bound against malformed grids, made opaque: read straight from the kernel arguments the compiler re-loaded it -
+    // a scalar memory load and its wait - at the head of EVERY step rather than keep it in a register)
+    uint32_t max_steps = P.max_steps;
+    asm volatile("" : "+s"(max_steps));
     for (unsigned iter = 0;; ++iter) {
         const bool need = nb >= 0;
         const unsigned long long needs = __builtin_amdgcn_ballot_w64(need);
         if (needs == 0ull) break;
-        if (iter >= P.max_steps) {
+        if (iter >= (C5_LOOP_TRIM ? max_steps : P.max_steps)) {
             if (need) n_seg |= kOverflowBit;
             break;
         }
@@ -865,7 +893,8 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
                 __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hs), static_cast<uint32_t>(static_cast<int>(heads & 1ull) - 1))));
         }
         // (kept in a scalar register by hand: as a plain min() the compiler compared it on the vector unit)
-        const int n_staged = __builtin_amdgcn_readfirstlane(n_runs < kStageSlots ? n_runs : kStageSlots);
+        const int n_runs_s = __builtin_amdgcn_readfirstlane(n_runs);  // (the count of a ballot: uniform; said so, it is compared on the scalar unit)
+        const int n_staged = n_runs_s < kStageSlots ? n_runs_s : kStageSlots;
 #if C5_WALK_STAMPS
         stat_iters += 1u;
         stat_lanes += static_cast<unsigned>(__popcll(needs));
@@ -905,7 +934,9 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
             for (int j = 0; j < kDmaPasses; ++j) id_of_pass[j] = static_cast<uint32_t>(((LdsInts)(uintptr_t)dma_id_at)[kDmaSlots * j]);
 #pragma unroll
             for (int j = 0; j < kDmaPasses; ++j) {
-                if (j == 0 || kDmaSlots * j < n_staged) {  // wave-uniform: does the pass reach a staged slot at all
+                // (the lanes' own test below says it all; a wave-uniform "does the pass reach a staged slot at all" in front of
+                // it cost three scalar instructions per step and saved a skipped branch in half of them)
+                if (C5_LOOP_TRIM || j == 0 || kDmaSlots * j < n_staged) {
                     if (dma_id_at < ids_end - 4u * kDmaSlots * j) {  // this lane's slot kDmaSlots j + s is staged (idle lanes: never)
                         const uint32_t off = (id_of_pass[j] << 7) + dma_off;
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rec_bytes + off),
@@ -929,7 +960,7 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
         if (!kEmitNow) {
             // (wave-uniform choice of the exp: every pending lane's argument within (-1/8, 0] -> the short series)
             const bool big_arg = pend && !(pend_o0.y * pend_dz < -kSmallExpArg);
-            const bool short_exp = __builtin_amdgcn_ballot_w64(big_arg) == 0ull;
+            const bool short_exp = SMALLEXP || __builtin_amdgcn_ballot_w64(big_arg) == 0ull;
             if (pend) {
                 if (ORDER == 0) {
                     if (pend_o0.y != 0.0)  // line.cpp:220-224
@@ -959,6 +990,8 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
 #if C5_WALK_STAMPS
         if (stamping_) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         C5_STAMP(3);  // loads landed, pieces parked in LDS
+#elif defined(C5_ISA_MARKERS)
+        C5_STAMP(3);
 #endif
 
         // 4. every ray fetches its cell: eight 16-byte reads (the planes it can leave through, the neighbours behind
@@ -967,8 +1000,7 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
             CellRegs cur;
             const V2* r = reinterpret_cast<const V2*>(reinterpret_cast<const char*>(my_stage) +
                                                       __umul24(static_cast<unsigned>(slot), kSlotStride * 16u));
-            const bool staged = slot < kStageSlots;
-            if (staged) {
+            auto read_staged = [&]() {
                 cur.r0 = as_d2(r[0]);
                 cur.r1 = as_d2(r[1]);
                 cur.r2 = as_d2(r[2]);
@@ -979,6 +1011,12 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
                 // previous step's emission is done) and only looked at again if this step contributes
                 pend_o0 = r[6];
                 pend_o1 = r[7];
+            };
+            if (C5_LOOP_TRIM && n_runs_s <= kStageSlots) {
+                // (wave-uniform, nine steps in ten: every distinct cell has a slot - no per-lane "is my cell staged" at all)
+                read_staged();
+            } else if (slot < kStageSlots) {
+                read_staged();
             } else {
                 load_cell(cur, P.xrec, nb);  // more distinct cells than slots: rare
                 pend_o0 = V2{cur.r6.a, cur.r6.b};
@@ -1026,7 +1064,7 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
             const uint32_t id = sg.w_out & kIdMask;
             int nxt = static_cast<int>(id);
             if (id == kNoCell || clip) {  // left the grid: re-entry of a non-convex grid?  (or reached the end of the job's slab)
-                const size_t lp = pixel_index();
+                const size_t lp = pixel_index_rare();
                 double w_cur = my_scur[lane];  // (the key of the entry the ray took last: only (re-)entries write it)
                 const double key_taken = w_cur;
                 bool skipped = false;
@@ -1057,6 +1095,8 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
 #if C5_WALK_STAMPS
         if (stamping_) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         C5_STAMP(4);  // record read back, geometry, exit face, (re-entry)
+#elif defined(C5_ISA_MARKERS)
+        C5_STAMP(4);
 #endif
     }
 #if C5_WALK_STAMPS
@@ -1086,7 +1126,7 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
 #endif
     if (pend) {  // the last step's contribution
         if (ORDER == 0) {
-            if (pend_o0.y != 0.0) I = reference_emission_step(I, pend_o0.y, pend_o1.y, pend_o1.x, pend_dz);
+            if (pend_o0.y != 0.0) I = reference_emission_step<SMALLEXP>(I, pend_o0.y, pend_o1.y, pend_o1.x, pend_dz);
         } else if (T >= P.t_cutoff) {
             const double ex = exp_nonpositive(-pend_o0.y * pend_dz);
             I = fma(T * pend_o1.x, 1.0 - ex, I);
@@ -1094,6 +1134,12 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
         }
     }
 
+    {   // ... and the deepest at which one of them ends (carry: where the ray left its last cell)
+        double hi = (n_seg & ~(kOverflowBit | kSkippedBit)) ? carry : -DBL_MAX;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) hi = fmax(hi, __shfl_xor(hi, d));
+        if (lane == 0 && hi > -DBL_MAX) atomicMax(&fc_job()->exit_max_key, depth_key(hi));
+    }
     if (SPLIT) {
         // The job's partial results, indexed tile * 64 + lane (whole 512-byte rows per array and wavefront), then the
         // tile's arrival count: the job that finds K - 1 others already there composes the K partials in depth order and
@@ -1159,11 +1205,13 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
     }
 
     if (P.row_cost) {
-        const int lrow = pixel_lrow();
+        int l = lane;
+        asm volatile("" : "+v"(l));  // (as in pixel_index_rare: nothing of this is kept across the loop)
+        const int lrow = ty * TH + (wave / TS::GX) * TS::WH + (l / TS::WW);
         unsigned rs = n_seg;
 #pragma unroll
         for (int d = TS::WW / 2; d >= 1; d >>= 1) rs += __shfl_xor(rs, d);
-        if ((lane % TS::WW) == 0 && rs && lrow < im.n_local_rows) atomicAdd(P.row_cost + lrow, rs);
+        if ((l % TS::WW) == 0 && rs && lrow < im.n_local_rows) atomicAdd(P.row_cost + lrow, rs);
     }
     const unsigned s_seg = wave_sum_u32(n_seg);
     const unsigned s_cov = wave_sum_u32(n_seg > 0 ? 1u : 0u);
@@ -1171,12 +1219,15 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
     const unsigned s_ovf = wave_sum_u32(overflow);
     const unsigned s_ent = wave_sum_u32(n_entries);
     const unsigned s_skip = static_cast<unsigned>(__popcll(__builtin_amdgcn_ballot_w64(skipped)));
+    unsigned s_longest = n_seg;  // the longest ray of the tile, in segments
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s_longest = max(s_longest, static_cast<unsigned>(__shfl_xor(static_cast<int>(s_longest), d)));
     if (lane == 0) {
         if (s_skip) {
             atomicAdd(&P.counters->overlap_rays, s_skip);
             atomicAdd(P.sticky + 2, s_skip);
         }
-        FrameCounters* const fc = P.counters + ((blockIdx.x * 4u + static_cast<unsigned>(wave)) % kCounterShards);
+        FrameCounters* const fc = fc_job();
         if (s_seg && P.sb_cost && P.xcd_mode == 2) {  // what this wavefront cost, to its row of super-blocks
             const int sb_row = ty / P.band_tiles;
             if (sb_row < kMaxSbRows) atomicAdd(P.sb_cost + sb_row, s_seg);
@@ -1184,6 +1235,7 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
         if (s_ent) atomicAdd(&fc->entries, static_cast<unsigned long long>(s_ent));
         if (s_seg) atomicAdd(&fc->segments, static_cast<unsigned long long>(s_seg));
         if (s_seg) atomicAdd(&fc->ray_tiles, 1u);
+        if (s_seg) atomicMax(&fc->seg_max, s_longest);
         if (n_step_wave) atomicAdd(&fc->steps, static_cast<unsigned long long>(n_step_wave));
         if (s_cov) atomicAdd(&fc->covered, static_cast<unsigned long long>(s_cov));
         if (s_sol) atomicAdd(&fc->solid_pixels, static_cast<unsigned long long>(s_sol));

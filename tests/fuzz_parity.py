@@ -61,6 +61,8 @@ def main():
     bad = 0
     for k in range(n_scenes):
         seed = seed0 + k
+        if k % 50 == 0:
+            print(f"... scene {k} of {n_scenes}, {bad} mismatching renders so far", flush=True)
         xyz, cells, alpha, q, rots, res, limit = scene(seed)
         try:
             ref = o.render(xyz, cells, alpha, q, rots, res[0], res[1], mg.REFERENCE_BOUNDS, alpha_limit=limit, threads=8)
@@ -78,11 +80,33 @@ def main():
             a, b = img.astype(np.float64), ref["image"].astype(np.float64)
             tol = 1e-5 * np.maximum(np.abs(a), np.abs(b)) + 1e-6 * np.abs(b).max()
             n_bad = int((np.abs(a - b) > tol).sum())
+            if st["segments"] > 0 and st["steps"] == 0:
+                bad += 1  # the walk declared the components interpenetrating (next_entry) and left the frame to bin_sort_resolve
+                print(f"seed {seed} lds {lds} order {order} tile {tile}: rendered by bin_sort_resolve, not by the walk", flush=True)
+                ctx.upload_grid(xyz, cells, alpha, q)  # (judge every variant anew)
             if n_bad or st["segments"] != ref["segments"] or st["covered_pixels"] != ref["covered"]:
                 bad += 1
                 print(f"seed {seed} lds {lds} order {order} tile {tile}: {n_bad} px beyond tolerance, "
                       f"S {st['segments']} vs {ref['segments']}, covered {st['covered_pixels']} vs {ref['covered']}, "
                       f"cells {len(cells)} res {res}", flush=True)
+        # the rays cut in slabs ("depth_split" forced: 2 to 6 slabs, planes from the view alone): same bar, same counts
+        ctx.set_option("lds_stage", 2); ctx.set_option("integration", 0); ctx.set_option("tile", 3)
+        ctx.set_option("stage_slots", 21 if seed % 2 else 14)
+        slabs = 2 + seed % 5
+        ctx.set_option("depth_split", slabs)
+        img = ctx.render(); st = ctx.stats()
+        ctx.set_option("depth_split", 0); ctx.set_option("stage_slots", 0)
+        a, b = img.astype(np.float64), ref["image"].astype(np.float64)
+        tol = 1e-5 * np.maximum(np.abs(a), np.abs(b)) + 1e-6 * np.abs(b).max()
+        n_bad = int((np.abs(a - b) > tol).sum())
+        if st["segments"] > 0 and st["steps"] == 0:
+            bad += 1
+            print(f"seed {seed} SPLIT in {slabs} slabs: rendered by bin_sort_resolve, not by the walk", flush=True)
+            ctx.upload_grid(xyz, cells, alpha, q)
+        if n_bad or st["segments"] != ref["segments"] or st["covered_pixels"] != ref["covered"]:
+            bad += 1
+            print(f"seed {seed} SPLIT in {slabs} slabs: {n_bad} px beyond tolerance, S {st['segments']} vs {ref['segments']}, "
+                  f"covered {st['covered_pixels']} vs {ref['covered']}, steps {st['steps']}, cells {len(cells)} res {res}", flush=True)
         # sharded renders of the same scene (what the ranks of a multi-GPU run do), reassembled on the host:
         # cyclic row tiles and contiguous blocks, random world size and tile height, product-default kernel
         from course5_amd import sharding
@@ -112,7 +136,7 @@ def main():
             if not np.array_equal(img2.view(np.uint32), full.view(np.uint32)):
                 bad += 1
                 print(f"seed {seed}: {name} shards (world {world}, tile_rows {tile_rows}) differ from the full frame", flush=True)
-    print(f"{n_scenes} scenes x ({len(VARIANTS)} variants + 2 sharded layouts): {bad} mismatching renders")
+    print(f"{n_scenes} scenes x ({len(VARIANTS)} variants + 1 render cut in slabs + 2 sharded layouts): {bad} mismatching renders")
     return bad
 
 if __name__ == "__main__":
