@@ -639,14 +639,17 @@ def main():
         pmc_stale = bool(pmc) and pmc.get("source_hash") != src_hash
         phases = (pmc or {}).get("phases")
         lim = (pmc or {}).get("limiter") or {}
-        bound_names = {"valu": "vector-instruction issue (VALU quad-cycles, no MFMA)", "salu": "scalar-instruction issue", "lds": "LDS",
+        bound_names = {"chain": "latency chain of a wavefront-step at 8 wavefronts per SIMD (no unit saturated: vector pipes ~55 % weighted by "
+                                "instruction cost, the CU's scalar unit ~65 %, LDS ~60 %, HBM 13-16 %; profiles/r04_walk_isa.md)",
+                       "valu": "vector-instruction issue (VALU quad-cycles, no MFMA)", "salu": "scalar-instruction issue", "lds": "LDS",
                        "l2": "L2 requests", "hbm": "hbm"}
         roofline = {
-            # `bound` names the unit the committed counters show busiest (profiles/<round>_pmc.md; `limiter` holds its
-            # fraction over the whole launch and while the wavefront slots are full, `phases` where a wavefront-step
-            # spends its cycles, `timeline` how the launch fills and drains).  HBM is NOT it (12 %: the 128 MB of
-            # per-view records are served from L2 / Infinity Cache): achieved / peak / frac stay the HBM-side figures
-            # the contract asks for — HBM bytes per launch over the live kernel time against 8 TB/s.
+            # `bound` says what binds the kernel by the committed instruments: the loop's instructions by class at their
+            # measured issue cost against the counters (profiles/<round>_walk_isa.md, _pmc.md; `limiter` holds the units'
+            # busy shares over the launch and while the wavefront slots are full), `phases` where a wavefront-step spends
+            # its cycles, `timeline` how the launch fills and drains.  HBM is NOT it (13 %: the 128 MB of per-view records
+            # are served from L2 / Infinity Cache): achieved / peak / frac stay the HBM-side figures the contract asks
+            # for — HBM bytes per launch over the live kernel time against 8 TB/s.
             "bound": bound_names.get(lim.get("name"), "hbm"),
             "nearest_roofline": "hbm", "kernel": "walk_composite",
             "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -706,6 +709,11 @@ def main():
                        "sweep": args.sweep, "solids": bool(args.solids),
                        "view_cache": ("on: the view of a -D sweep is fixed (per-view data built twice, then reused)" if args.sweep == "D"
                                       else "off: every timed frame does its whole per-view setup"),
+                       "walk_kernel": ("walk_composite_lds<3, 0, true, 14, SMALLEXP = true>: the instantiation without the general exp, taken while "
+                                       "min(alpha limit, largest alpha) x longest cell edge < 1/8 (this workload: 0.10; with --alpha_limit 3.0 on the "
+                                       "same grid 0.12).  The general instantiation (SMALLEXP = false: wave-uniform choice between the short series "
+                                       "and the full exp) runs the same frame about 3 % slower (0.474 against 0.460 ms, round 3)"),
+                       "depth_split": "0 (per frame): this frame's jobs fill the wavefront slots 2.5 times over, its rays stay whole",
                        "rays_per_gpu": P_total // world,
                        "frames_timed": frames},
             "roofline": roofline,

@@ -105,29 +105,48 @@ def write_roofline(tag, walk, c):
     tl = extra.get("walk_timeline")
     if tl:
         out["timeline"] = tl
-    busiest = max(((k, v["frac"]) for k, v in units.items() if k in ("valu", "lds", "l2", "hbm", "salu") and v.get("frac")),
-                  key=lambda kv: kv[1], default=None)
-    if busiest:
-        lim = {"name": busiest[0], "frac": busiest[1]}
-        if tl and tl.get("steady_over_mean"):
-            # the launch spends its last quarter draining (one wavefront lives a third of the launch): while the slots
-            # are full the units are busier than their average over the launch by the ratio of the step rates
-            lim["steady_state_frac"] = min(1.0, busiest[1] * tl["steady_over_mean"])
-            per_step = (get("SQ_INSTS_VALU") or 0.0) / tl["wave_steps"] if tl.get("wave_steps") else None
-            lim["valu_per_wave_step"] = per_step
-            lim["note"] = ("the busiest unit by its counter, averaged over the launch and (steady_state_frac) while the wavefront slots "
-                           "are full (every vector instruction of a wave64 holds its SIMD for a quad-cycle, fp64 or not: "
-                           "SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU; valu_per_wave_step of them per wavefront-step).  Two limits meet in "
-                           "this kernel: the vector issue of the resident wavefronts, and the time ONE wavefront needs for a step - its "
-                           "dependent chain (phases: LDS round trips, the staging loads, ~170 instructions in sequence); a lone "
-                           "wavefront steps no faster (profiles/" + tag + "_share_probe.md).  On the four-plane records of rounds 1-2 "
-                           "(84 vector instructions per step, seven wavefronts) fewer instructions alone, an eighth wavefront alone and "
-                           "frames overlapped on a second stream bought 0 / 0 / +2.4 %; the exit records (three planes, one line per "
-                           "cell) cut instructions, LDS bytes and registers together, and THEN the eighth wavefront paid: walk 0.540 -> "
-                           "0.474 ms (DESIGN.md section 4)")
-        else:
-            lim["note"] = "the busiest unit by its counter over the whole launch"
-        out["limiter"] = lim
+    # What binds the kernel: not the counter that reads highest under a flat 4-cycles-per-instruction
+    # formula, but the units' busy shares with every instruction class at its measured issue cost
+    # (scripts/walk_isa.py -> profiles/<tag>_walk_isa_counts.json: the loop's instructions per wavefront-step by class),
+    # in the steady state (while the wavefront slots are full), beside what a wavefront-step costs at 2 .. 8 wavefronts
+    # per SIMD (scripts/share_timeline.py).
+    lim = {}
+    try:
+        with open(os.path.join(PROF, f"{tag}_walk_isa_counts.json")) as f:
+            isa = json.load(f)
+        per_step = {}
+        for ph in isa["main"].values():
+            for cls, n in ph.items():
+                per_step[cls] = per_step.get(cls, 0) + n
+        rates = isa["rates"]
+        lim["instructions_per_wave_step"] = per_step
+        lim["issue_cycles"] = rates
+    except Exception:  # noqa: BLE001
+        per_step, rates = None, None
+    steady = (tl or {}).get("steady_over_mean") or 1.0
+    if per_step and cycles and tl and tl.get("wave_steps"):
+        ws = tl["wave_steps"]
+        valu_cyc = (per_step.get("valu64", 0) * rates["valu64"] + per_step.get("valu32", 0) * rates["valu32"]) * ws
+        lim["valu_busy_weighted"] = {"launch": valu_cyc / (cycles * n_simd), "steady": min(1.0, valu_cyc / (cycles * n_simd) * steady),
+                                     "what": "(fp64 vector instructions x 4 + 32-bit ones x 2 cycles) per wavefront-step x wavefront-steps / "
+                                             "(cycles x 1024 SIMDs): not an upper bound like units.valu (which charges every vector instruction 4)"}
+        scal = (per_step.get("salu", 0) + per_step.get("branch", 0)) * ws
+        lim["scalar_busy_per_cu"] = {"launch": scal / (cycles * n_cu), "steady": min(1.0, scal / (cycles * n_cu) * steady),
+                                     "what": "scalar + branch instructions per wavefront-step x wavefront-steps / (cycles x 256 CUs): ONE scalar unit "
+                                             "per CU serves its four SIMDs, one instruction per cycle"}
+    for k in ("lds", "l2", "hbm", "salu"):
+        if units.get(k, {}).get("frac"):
+            lim.setdefault("units_steady", {})[k] = min(1.0, units[k]["frac"] * steady)
+    lim["name"] = "chain"
+    lim["frac"] = (lim.get("valu_busy_weighted") or {}).get("steady")
+    lim["note"] = ("No unit is saturated while the wavefront slots are full: vector pipes (weighted by what instructions cost) about half, "
+                   "the CU's scalar unit and its LDS 55-75 %, L2 and HBM 12-16 %.  What a step costs is its dependent chain - four LDS round "
+                   "trips, the two LDS-DMA pieces, ~170 instructions in order: phases - stretched by the queueing at those shared units: the "
+                   "same step takes 843 ns with 2 wavefronts per SIMD, 984 with 4, 1 118 with 6, 1 221 with 7 (profiles/" + tag +
+                   "_share_timeline.md), so eight wavefronts deliver 6.6 times what one does, not 8.  Hiding a phase (emission deferred behind the "
+                   "loads: -1.4 %) or trimming one unit (8 scalar instructions and a scalar load per step: +0.5 %) does not shorten it "
+                   "(profiles/experiments.md); the 128-byte exit records of round 3 cut LDS bytes, vector and scalar work together: 0.540 -> 0.456 ms.")
+    out["limiter"] = lim
     with open(os.path.join(PROF, f"roofline{SUFFIX}.json"), "w") as f:
         json.dump(out, f, indent=1)
     lines = [f"walk_composite per launch: {cycles:.4g} shader cycles" if cycles else ""]

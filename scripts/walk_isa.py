@@ -122,7 +122,11 @@ for i in range(ma, mb + 1):
         continue
     j = labels[m.group(1)]
     text = "\n".join(marked[i + 1:j])
-    if any(r in text for r in RARE) and "global_load_lds_dwordx4" not in text and "ds_read_b128" not in text.replace("", ""):
+    if "global_load_lds_dwordx4" in text or "v_fmac_f64" in text:  # (a region that holds the staging loads or the three planes IS the main path)
+        continue
+    # (a skipped region that holds the per-lane fall-back loads is the arm for "more distinct cells than slots", its own
+    # copy of the eight LDS reads included: the main path has another copy behind the wave-uniform test)
+    if "global_load_dwordx4 v[" in text or (any(r in text for r in RARE) and "ds_read_b128" not in text):
         rare_lines.update(range(i + 1, j))
 # (the per-lane fall-back sits in the 'then' arm of a branch whose 'else' arm holds the eight ds_read_b128: only that arm is rare)
 for (x, y) in block_ranges(marked, ma, mb):
