@@ -42,9 +42,13 @@ enum {
     C5_ERR_MESH = 4,        /* c5_face_adjacency: a face is shared by more than two cells */
     C5_ERR_NO_DEVICE = 5,   /* no usable GPU */
     C5_ERR_WALK = 6,        /* a ray exceeded the step bound (malformed grid) */
-    C5_RETRY = 7            /* an internal buffer was too small and has been grown: EVERY frame enqueued since
-                               the last call that waited for the stream is incomplete and must not be used;
-                               call c5_render_device again.  Reported by every call that waits for the stream
+    C5_RETRY = 7            /* EVERY frame enqueued since the last call that waited for the stream is incomplete or
+                               wrong and must not be used; call c5_render_device again.  Two causes, both settled by the
+                               library before it says so: an internal buffer was too small and has been grown; or the
+                               walk met rays that had to SKIP a boundary entry inside a stretch of cells they had walked
+                               - components of the grid that share no face interpenetrate, which the reference simply
+                               bins and sorts (plane.cpp:184-192, line.cpp:138) - and the grid is rendered with
+                               "algorithm" 1 from now on.  Reported by every call that waits for the stream
                                (c5_synchronize, c5_get_stats, c5_set_stream, c5_get_row_costs,
                                c5_download_view_points, c5_render_host_wait); c5_render retries by itself. */
 };
@@ -110,7 +114,8 @@ int c5_set_stream(c5_context* ctx, void* hip_stream);  /* waits for the old stre
  * cell_vert[n_cells][4] point ids, alpha/q[n_cells] = AbsorpCoef / radEnLooseRate
  * (object3d_accretion_disk.cpp:4).  Points with equal coordinates are welded (c5_weld_points), then the
  * face adjacency is built; n_cells must be < 2^28 (line.hpp:71-79).  A grid in which some face belongs to more than two cells cannot be walked:
- * it is accepted and rendered with "algorithm" 1 (see c5_set_option). */
+ * it is accepted and rendered with "algorithm" 1 (see c5_set_option); so is, from the first frame that shows it, a grid
+ * whose components share no face but interpenetrate (C5_RETRY once, see above). */
 int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int32_t* cell_vert,
                    int64_t n_cells, const double* alpha, const double* q);
 /* Replace only the cell scalars of the uploaded grid. */
@@ -150,6 +155,16 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  once the transmittance T falls below "transmittance_cutoff" (default 1e-12,
  *                  0 disables).  Both agree to rounding wherever the reference's recurrence is
  *                  well conditioned (it is not for DBL_EPSILON <= alpha < ~1e-8).
+ *   "depth_split"  0 (default): a frame whose rays do not fill the GPU's wavefront slots - a small image, one GPU's rows of
+ *                  a frame - and are long enough is rendered with every ray cut at K - 1 planes of constant depth (K <= 4,
+ *                  chosen from the statistics of the frame before): K jobs per 8x8 pixel tile walk the K parts at once and
+ *                  the partial integrals are composed in depth order (tau = sum; I <- exp(-tauc_s) I + b_s: the recurrence
+ *                  of line.cpp:206-225 is affine in I).  Same segment counts; I differs from the whole-ray walk in its
+ *                  rounding ORDER only (~1e-16) - which is why a grid with a clamped alpha in [DBL_EPSILON, 1e-6), where
+ *                  the reference's recurrence is dominated by its own cancellation error, is never cut.  1: never.
+ *                  2..8: always that many slabs, with planes that depend on the view alone (renders of different rows of
+ *                  one frame are bit-equal only at the same slab count).  Default tile shape, "lds_stage" 2,
+ *                  "integration" 0 and "xcd_mode" 2 only; whole rays otherwise.  DESIGN.md section 4.3.
  *   "algorithm"    0 (default for conforming grids): face-adjacency walk.  1: bin_sort_resolve, the
  *                  reference's own algorithm on the GPU (every face of every cell scan-converted onto
  *                  the pixels, per-pixel sort by z, integrate) — handles tet soups, overlapping and
@@ -232,10 +247,12 @@ int c5_synchronize(c5_context* ctx);
  * pageable buffer makes the copy synchronous.  At most C5_HOST_RING frames may be outstanding; every
  * c5_render_host_async is paired, in order, with one c5_render_host_wait, which returns when THAT frame's
  * pixels are in out_host.  C5_RETRY from the wait: that frame and every frame enqueued after it are
- * incomplete (an internal buffer was too small and has been grown) — wait for the rest, discard, render again.
- * Whichever call notices the overflow first (c5_get_stats, c5_get_row_costs, c5_synchronize between an async and
- * its wait included) settles it and returns C5_RETRY once; the waits of every frame outstanding at that moment
- * return C5_RETRY as well, whatever their own status snapshots read. */
+ * incomplete (an internal buffer was too small and has been grown, or the grid turned out to need "algorithm" 1) —
+ * wait for the rest, discard, render again.  A frame's status is read from ITS OWN counters (every frame of the ring
+ * keeps its statistics apart: no frame in flight can add to another's).  Whichever call notices a failure first
+ * (c5_get_stats, c5_get_row_costs, c5_synchronize between an async and its wait included) settles it and returns
+ * C5_RETRY once; the waits of every frame outstanding at that moment return C5_RETRY as well, whatever their own
+ * status words read; c5_last_error names the words. */
 #define C5_HOST_RING 3
 int c5_render_host_async(c5_context* ctx, float* out_host);
 int c5_render_host_wait(c5_context* ctx);
