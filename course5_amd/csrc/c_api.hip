@@ -122,6 +122,8 @@ struct FrameSlot {
     const c5::FrameCounters* raster_counters = nullptr;  // device: counters of the frame whose raster built the slot's entry lists
     // "depth_split" (device_types.hpp: SplitParams)
     DeviceBuffer plane_cell, straddle, straddle_count, partials, arrivals;
+    DeviceBuffer bfrec;          // BFaceRecord per boundary face (build_records -> entry_raster_rec), stamped with ...
+    uint32_t bf_seq = 0;         // ... the number of the frame that wrote it
     int split_k = 0;             // slabs the buffers above are laid out for (0: none)
     int64_t split_px = 0, split_tiles = 0, split_cells = 0;
     uint64_t split_seq = 0;      // raster frames so far: stamp = seq % 15 + 1, counter half = seq & 1
@@ -163,6 +165,7 @@ struct c5_context {
     uint64_t setup_epoch = 1;  // bumped by everything but the view, the alpha limit and the solids that the per-view data depend on
     int solid_interior_faces = 0;  // 1: interior faces are rastered too (they cover nothing the others do not; testing)
     int depth_split = 0;    // "depth_split": 0 = chosen per frame (split_auto_k), 1 = never, 2..8 = that many slabs
+    int entry_records = 1;  // "entry_records": build_records leaves a record per boundary face for the entry raster (0: the raster gathers)
     int split_auto_k = 1;   // what the last finished frame suggests (finish_frame)
     bool ray_depth_known = false;  // ... and the depths its rays ran between (walk coordinate)
     double ray_depth_lo = 0.0, ray_depth_hi = 0.0;
@@ -725,7 +728,28 @@ int enqueue_frame(c5_context* ctx, float2* out_dev, c5::FrameCounters* own_count
         C5_HIP(ctx, hipEventRecord(ctx->fork_ev, s));
         C5_HIP(ctx, hipStreamWaitEvent(e, ctx->fork_ev, 0));
     }
+    // the frame's uniform entry-key slack (walk_common.hpp: entry_key_slack): a fraction of the GRID's size — not of
+    // the image domain's: a slack larger than a whole ray would let a pixel that two boundary faces both claim (its
+    // centre exactly on their common edge) walk the same cells twice — plus the rounding of an absolute depth
+    const double key_slack = !ctx->entry_key ? -1.0 : c5::kEntryKeySlack * ctx->grid_diagonal + 0x1p-40 * ctx->coord_max;
     if (!(ctx->fuse_setup && !side && g.n_cells > 0) && !reuse) {
+        if (ctx->entry_records && !ctx->fuse_setup && !side && g.n_bfaces > 0) {  // (the raster must run BEHIND build_records)
+            // build_records leaves a 96-byte record per boundary face a ray can enter through (entry_raster_rec)
+            if (fs.bfrec.bytes < static_cast<size_t>(g.n_bfaces) * sizeof(c5::BFaceRecord)) {
+                C5_HIP(ctx, fs.bfrec.ensure(static_cast<size_t>(g.n_bfaces) * sizeof(c5::BFaceRecord)));
+                C5_HIP(ctx, hipMemsetAsync(fs.bfrec.ptr, 0, fs.bfrec.bytes, s));
+                fs.bf_seq = 0;
+            }
+            fs.bf_seq += 1;
+            if (fs.bf_seq == 0) {  // (4 billion frames on: no stale record may look current)
+                C5_HIP(ctx, hipMemsetAsync(fs.bfrec.ptr, 0, fs.bfrec.bytes, s));
+                fs.bf_seq = 1;
+            }
+            g.bfrec = fs.bfrec.as<c5::BFaceRecord>();
+            g.bf_seq = fs.bf_seq;
+            g.bf_want_upper = ctx->order != 0;
+            g.bf_key_slack = key_slack;
+        }
         // (a cell's optics ride in its record since round 3 — one line per cell and step — and are rewritten with it)
         c5::launch_build_records(s, g, ctx->alpha_limit, ctx->order);
         c5::launch_plane_raster(s, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im);  // ("depth_split"; nothing otherwise)
@@ -733,10 +757,6 @@ int enqueue_frame(c5_context* ctx, float2* out_dev, c5::FrameCounters* own_count
     const bool fused = ctx->fuse_setup && !side && g.n_cells > 0;
     if (!fused) C5_HIP(ctx, mark(2, s));
     // boundary entries: one raster pass (per-pixel count + first entry + overflow chain)
-    // the frame's uniform entry-key slack (walk_common.hpp: entry_key_slack): a fraction of the GRID's size — not of
-    // the image domain's: a slack larger than a whole ray would let a pixel that two boundary faces both claim (its
-    // centre exactly on their common edge) walk the same cells twice — plus the rounding of an absolute depth
-    const double key_slack = !ctx->entry_key ? -1.0 : c5::kEntryKeySlack * ctx->grid_diagonal + 0x1p-40 * ctx->coord_max;
     if (!fs.head_clean && !reuse) C5_HIP(ctx, hipMemsetAsync(fs.head.ptr, 0, static_cast<size_t>(padded) * sizeof(c5::EntryHead), e));
     fs.head_clean = false;
     if (fused) {
@@ -1142,7 +1162,7 @@ void c5_destroy(c5_context* ctx) {
     for (FrameSlot& fs : ctx->slots) {
         DeviceBuffer* sb[] = {&fs.vx, &fs.vy, &fs.vz, &fs.rec, &fs.count, &fs.head, &fs.first, &fs.pool,
                               &fs.mask, &fs.counters, &fs.row_cost, &fs.sb, &fs.plane_cell, &fs.straddle, &fs.straddle_count,
-                              &fs.partials, &fs.arrivals};
+                              &fs.partials, &fs.arrivals, &fs.bfrec};
         for (DeviceBuffer* b : sb) b->release();
         if (fs.host_counters) (void)hipHostFree(fs.host_counters);
         for (auto& ev : fs.ev)
@@ -1270,7 +1290,12 @@ int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int3
     }
     if (n_cells > 0) {
         C5_HIP(ctx, hipMemcpy(ctx->cell_vert.ptr, cell_vert, cb * 16, hipMemcpyHostToDevice));
-        C5_HIP(ctx, hipMemcpy(ctx->cell_adj.ptr, adj.data(), cb * 16, hipMemcpyHostToDevice));
+        // the device's copy names every boundary face by its index in the sorted boundary-face list: -(i + 2) where the
+        // host API says -1 (build_records leaves the face's record in slot i: device_types.hpp: BFaceRecord)
+        std::vector<int32_t> adj_dev(adj);
+        for (size_t i = 0; i < bfaces.size(); ++i)
+            adj_dev[static_cast<size_t>(bfaces[i] >> 2) * 4 + (bfaces[i] & 3u)] = -static_cast<int32_t>(i) - 2;
+        C5_HIP(ctx, hipMemcpy(ctx->cell_adj.ptr, adj_dev.data(), cb * 16, hipMemcpyHostToDevice));
         C5_HIP(ctx, hipMemcpy(ctx->alpha.ptr, alpha, cb * 8, hipMemcpyHostToDevice));
         C5_HIP(ctx, hipMemcpy(ctx->q.ptr, q, cb * 8, hipMemcpyHostToDevice));
     }
@@ -1585,6 +1610,8 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
         for (Solid& so : ctx->solids) so.own_mask_ready = false, so.unchanged_frames = 0, so.seen_generation = ~uint64_t{0};
     } else if (n == "view_cache") {
         ctx->view_cache = static_cast<int>(value) != 0;
+    } else if (n == "entry_records") {
+        ctx->entry_records = static_cast<int>(value) != 0;
     } else if (n == "depth_split") {
         if (value < 0 || value > c5::kMaxSlabs || value != std::floor(value))
             return fail(ctx, C5_ERR_INVALID, "depth_split must be 0 (per frame), 1 (never) or 2..%d slabs", c5::kMaxSlabs);

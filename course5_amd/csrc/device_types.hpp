@@ -3,7 +3,7 @@
 // Persistent grid (uploaded once, SoA, coalesced for the per-frame setup kernels):
 //   px/py/pz[n_pts]      fp64   raw vertex coordinates
 //   cell_vert[n_cells]   int4   cell -> vertex ids          (tetra.hpp:42 replaced by indices)
-//   cell_adj[n_cells]    int4   cell -> neighbour across face f (-1 = boundary)
+//   cell_adj[n_cells]    int4   cell -> neighbour across face f; boundary: -(i + 2), i = the face's index in bface[] (host API: -1)
 //   alpha/q[n_cells]     fp64   AbsorpCoef / radEnLooseRate (object3d_accretion_disk.cpp:4)
 //   bface[n_bfaces]      u32    (cell << 2 | face) of every face without a neighbour
 //
@@ -89,6 +89,18 @@ struct alignas(16) Entry {
     int32_t next;
 };
 constexpr int kEntrySlackShift = 28;
+// What entry_raster_rec needs of one boundary face, left by build_records for the faces a ray can ENTER through under
+// this view (the cell's record is being built anyway: vertices and face planes are in registers there): the face's three
+// projected vertices, its plane z = pc + pgx (x - x0) + pgy (y - y0), the cell word of its entries (id + key exponent) and
+// the number of the frame that wrote it - a record of another frame (a face turned away, a cell outside this context's
+// rows) is not rastered.  Slot i belongs to the i-th face of the sorted boundary-face list (GridView::bface); the
+// device's adjacency table holds -(i + 2) where the host's holds -1.
+struct alignas(16) BFaceRecord {
+    double ax, ay, bx, by, cx, cy, x0, y0, pc, pgx, pgy;
+    uint32_t cell_word;
+    uint32_t seq;
+};
+static_assert(sizeof(BFaceRecord) == 96, "BFaceRecord is six 16-byte units");
 // Per pixel and frame: number of entries and the head of the pixel's overflow chain (pool slot + 1).
 // Cleared to zero before every raster pass.
 struct alignas(8) EntryHead {

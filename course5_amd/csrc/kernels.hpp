@@ -22,6 +22,11 @@ struct GridView {  // device pointers of the persistent grid + per-view buffers
     // only cells whose projected y-extent meets [cull_y_lo, cull_y_hi] can be reached by a ray of this context
     double cull_y_lo = 0, cull_y_hi = 0;
     SplitParams split{};  // "depth_split": build_records lists the cells that straddle a cutting plane (n_slabs > 1)
+    // boundary-face records for entry_raster_rec (nullptr: none wanted), stamped bf_seq; which faces a ray enters through
+    BFaceRecord* bfrec = nullptr;
+    uint32_t bf_seq = 0;
+    int32_t bf_want_upper = 0;
+    double bf_key_slack = 0.0;
 };
 
 struct WalkParams {
@@ -107,6 +112,7 @@ void launch_mask_overlay(hipStream_t s, const uint32_t* src, uint32_t* dst, int6
 // absolute depth, c_api.hip), the same for every face of a frame
 constexpr double kEntryKeySlack = 0x1p-24;
 void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, int order);
+// (g.bfrec set: from the face records build_records left - entry_raster_rec; else every face finds its own vertices)
 void launch_entry_lists(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
                         const ImageParams& im, EntryHead* head, Entry* first, Entry* pool, int64_t capacity,
                         FrameCounters* counters, unsigned* sticky, int want_upper, double key_slack);

@@ -46,7 +46,7 @@ __device__ __forceinline__ FacePlane face_plane(const double (&p)[4][3], int f) 
 
 template <bool kOptics>
 __device__ __forceinline__ bool build_cell_impl(const GridView& g, double alpha_limit, int order, int64_t cell,
-                                                CellRecord& r, CellOptics& o, double (*verts)[3]);
+                                                CellRecord& r, CellOptics& o, double (*verts)[3], int4* adj_out = nullptr);
 // verts (optional): the cell's four transformed vertices
 __device__ __forceinline__ bool build_cell(const GridView& g, double alpha_limit, int order, int64_t cell, CellRecord& r,
                                            CellOptics& o, double (*verts)[3] = nullptr) {
@@ -76,7 +76,7 @@ __device__ __forceinline__ CellOptics cell_optics(const GridView& g, double alph
 // Records of one cell; false if the cell is outside this context's row band (nothing to store).
 template <bool kOptics>
 __device__ __forceinline__ bool build_cell_impl(const GridView& g, double alpha_limit, int order, int64_t cell,
-                                                CellRecord& r, CellOptics& o, double (*verts)[3]) {
+                                                CellRecord& r, CellOptics& o, double (*verts)[3], int4* adj_out) {
     const int4 cv = g.cell_vert[cell];
     const int vid[4] = {cv.x, cv.y, cv.z, cv.w};
     double p[4][3];
@@ -88,6 +88,7 @@ __device__ __forceinline__ bool build_cell_impl(const GridView& g, double alpha_
     const double cy_hi = fmax(fmax(p[0][1], p[1][1]), fmax(p[2][1], p[3][1]));
     if (cy_hi < g.cull_y_lo || cy_lo > g.cull_y_hi) return false;
     const int4 adj = g.cell_adj[cell];
+    if (adj_out) *adj_out = adj;
     const int nb[4] = {adj.x, adj.y, adj.z, adj.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -407,6 +408,16 @@ __device__ __forceinline__ uint32_t entry_key_exponent(double gx, double gy, dou
     return static_cast<uint32_t>(e < 1 ? 1 : (e > 15 ? 15 : e));
 }
 
+// entry_key_exponent of a face from its three vertices (extent: of the face along x, y and z; coord: its largest |x|, |y|)
+__device__ __forceinline__ uint32_t face_key_exponent(double ax, double ay, double az, double bx, double by, double bz, double cx, double cy,
+                                                      double cz, double gx, double gy, double base) {
+    const double xmin = fmin(ax, fmin(bx, cx)), xmax = fmax(ax, fmax(bx, cx));
+    const double ymin = fmin(ay, fmin(by, cy)), ymax = fmax(ay, fmax(by, cy));
+    const double extent = (xmax - xmin) + (ymax - ymin) + (fmax(az, fmax(bz, cz)) - fmin(az, fmin(bz, cz)));
+    const double coord = fmax(fmax(fabs(xmin), fabs(xmax)), fmax(fabs(ymin), fabs(ymax)));
+    return entry_key_exponent(gx, gy, extent, coord, base);
+}
+
 struct RasterArgs {
     const double* Xtab;
     const double* Ytab;
@@ -421,18 +432,14 @@ struct RasterArgs {
     double key_slack;  // the frame's uniform entry-key slack (entry_key_exponent's base; <= 0: none)
 };
 
+__device__ __forceinline__ void raster_face(const RasterArgs& A, int lane, int64_t face_idx, double ax, double ay, double bx, double by,
+                                            double cx, double cy, double x0, double y0, double pc, double pgx, double pgy, uint32_t cell_word);
+
 // The work of one workgroup (four boundary faces); `block` is its index among the raster workgroups, so that
-// the same body serves the stand-alone kernel and the fused per-view setup launch.
+// the same body serves the stand-alone kernel and the fused per-view setup launch.  This form finds a face's vertices
+// itself (boundary face -> cell -> four vertex ids -> twelve coordinates: three dependent rounds of loads);
+// entry_raster_rec below starts from the record build_records left for the face.
 __device__ __forceinline__ void entry_raster_block(const GridView& g, const RasterArgs& A, unsigned block) {
-    const double* __restrict__ Xtab = A.Xtab;
-    const double* __restrict__ Ytab = A.Ytab;
-    const ImageParams& im = A.im;
-    EntryHead* __restrict__ head = A.head;
-    Entry* __restrict__ first = A.first;
-    Entry* __restrict__ pool = A.pool;
-    const int64_t capacity = A.capacity;
-    FrameCounters* counters = A.counters;
-    unsigned* sticky = A.sticky;
     const int want_upper = A.want_upper;
     const int lane = threadIdx.x & 63;
     const int64_t face_idx = block * 4ll + (threadIdx.x >> 6);
@@ -481,6 +488,25 @@ __device__ __forceinline__ void entry_raster_block(const GridView& g, const Rast
         cz = i2 == 2 ? p[2][2] : p[3][2];
     }
 
+    // an entry carries its face's own depth; how far behind it the entry is KEYED is the frame's uniform slack times
+    // 2^k, k > 0 only for a face steep against the rays: once per face, in the top bits of the cell word
+    const uint32_t cell_word = cell | (face_key_exponent(ax, ay, az, bx, by, bz, cx, cy, cz, fp.gx, fp.gy, A.key_slack) << kEntrySlackShift);
+    raster_face(A, lane, face_idx, ax, ay, bx, by, cx, cy, p[0][0], p[0][1], fp.c, fp.gx, fp.gy, cell_word);
+}
+
+// The pixels of one boundary face (one wavefront): see entry_raster above.  (x0, y0): the origin the face's plane
+// (pc, pgx, pgy) is written about.
+__device__ __forceinline__ void raster_face(const RasterArgs& A, int lane, int64_t face_idx, double ax, double ay, double bx, double by,
+                                            double cx, double cy, double x0, double y0, double pc, double pgx, double pgy, uint32_t cell_word) {
+    const double* __restrict__ Xtab = A.Xtab;
+    const double* __restrict__ Ytab = A.Ytab;
+    const ImageParams& im = A.im;
+    EntryHead* __restrict__ head = A.head;
+    Entry* __restrict__ first = A.first;
+    Entry* __restrict__ pool = A.pool;
+    const int64_t capacity = A.capacity;
+    FrameCounters* counters = A.counters;
+    unsigned* sticky = A.sticky;
     const double xmin = fmin(ax, fmin(bx, cx)), xmax = fmax(ax, fmax(bx, cx));
     const double ymin = fmin(ay, fmin(by, cy)), ymax = fmax(ay, fmax(by, cy));
     // conservative pixel box: floor / ceil already include a pixel on either side whose centre lies outside
@@ -503,14 +529,6 @@ __device__ __forceinline__ void entry_raster_block(const GridView& g, const Rast
     const unsigned bw = static_cast<unsigned>(c1 - c0 + 1);
     const unsigned n_box = bw * static_cast<unsigned>(lr1 - lr0 + 1);  // <= pixels of the image: fits 32 bits
 
-    const double x0 = p[0][0], y0 = p[0][1];
-    // an entry carries its face's own depth; how far behind it the entry is KEYED is the frame's uniform slack times
-    // 2^k, k > 0 only for a face steep against the rays: once per face, in the top bits of the cell word
-    const double extent = (xmax - xmin) + (ymax - ymin) + (fmax(az, fmax(bz, cz)) - fmin(az, fmin(bz, cz)));
-    const double coord = fmax(fmax(fabs(xmin), fabs(xmax)), fmax(fabs(ymin), fabs(ymax)));
-    const uint32_t cell_word = cell | (entry_key_exponent(fp.gx, fp.gy, extent, coord, A.key_slack) << kEntrySlackShift);
-    const double pc = fp.c, pgx = fp.gx, pgy = fp.gy;
-
     // The raster is bound by vector instructions (the box of a face holds 2.5x the pixels of the face), so
     // the per-pixel work is kept small: the three edge functions as planes about vertex a (two fused
     // multiply-adds each; which of two faces claims a pixel within rounding of their common edge was never
@@ -530,6 +548,16 @@ __device__ __forceinline__ void entry_raster_block(const GridView& g, const Rast
 #define C5_RASTER_CHUNKS 2
 #endif
     constexpr int kChunks = C5_RASTER_CHUNKS;
+    // The box's pixel coordinates once, one column and one row per lane, handed round the wavefront by lane permutes: read
+    // from the tables per chunk they were a dependent load in front of every chunk's atomics (round 4; a box wider or
+    // taller than 64 pixels - a face that spans a sixth of the image - reads the tables as before).
+    const unsigned n_rows_box = static_cast<unsigned>(lr1 - lr0 + 1);
+    const bool by_permute = bw <= 64u && n_rows_box <= 64u;
+    double x_of_lane = 0.0, y_of_lane = 0.0;
+    if (by_permute) {
+        x_of_lane = Xtab[c0 + static_cast<int>(min(static_cast<unsigned>(lane), bw - 1u))];
+        y_of_lane = Ytab[global_row_of(im, lr0 + static_cast<int>(min(static_cast<unsigned>(lane), n_rows_box - 1u)))];
+    }
     for (unsigned base = 0; base < n_box; base += 64u * kChunks) {
         bool in[kChunks];
         size_t lp[kChunks];
@@ -541,7 +569,8 @@ __device__ __forceinline__ void entry_raster_block(const GridView& g, const Rast
             in[k] = false;
             lp[k] = 0;
             z[k] = 0.0;
-            if (idx < n_box) {
+            if (base + 64u * k >= n_box) continue;  // (wave-uniform: the permutes below want every lane)
+            {
                 unsigned qrow, rcol;
                 if (small_box) {
                     qrow = static_cast<unsigned>(static_cast<float>(idx) * inv_bw);
@@ -558,11 +587,19 @@ __device__ __forceinline__ void entry_raster_block(const GridView& g, const Rast
                     qrow = idx / bw;
                     rcol = idx - qrow * bw;
                 }
+                const bool live = idx < n_box;
+                if (!live) qrow = 0u, rcol = 0u;
                 const int lrow = lr0 + static_cast<int>(qrow);
-                const int row = global_row_of(im, lrow);
                 const int col = c0 + static_cast<int>(rcol);
-                {
-                    const double x = Xtab[col], y = Ytab[row];
+                double x, y;
+                if (by_permute) {
+                    x = __shfl(x_of_lane, static_cast<int>(rcol));
+                    y = __shfl(y_of_lane, static_cast<int>(qrow));
+                } else {
+                    x = Xtab[col];
+                    y = Ytab[global_row_of(im, lrow)];
+                }
+                if (live) {
                     // closed point-in-triangle test, either winding
                     const double dxa = x - ax, dya = y - ay;
                     const double e0 = fma(ea0, dxa, eb0 * dya);

@@ -39,7 +39,7 @@ constexpr int kRecPad = 9;  // 16-byte units per record in LDS: 8 + 1 pad (confl
 // rounding of a point-in-cell test, generously — a claim this far off moves the start of one chord by as much.
 __device__ __forceinline__ double plane_tolerance(double coord, double extent) { return 64.0 * DBL_EPSILON * (coord + extent); }
 
-template <bool SPLIT>
+template <bool SPLIT, bool BF>
 __device__ __forceinline__ void build_records_block(const GridView& g, double alpha_limit, int order, unsigned block,
                                                     Q4 (*s_rec)[64 * kRecPad]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -49,9 +49,40 @@ __device__ __forceinline__ void build_records_block(const GridView& g, double al
     CellRecord r;
     CellOptics o;
     double verts[4][3];
-    if (valid) valid = build_cell_impl<true>(g, alpha_limit, order, cell, r, o, SPLIT ? verts : nullptr);
+    int4 adj = make_int4(0, 0, 0, 0);
+    if (valid) valid = build_cell_impl<true>(g, alpha_limit, order, cell, r, o, (SPLIT || BF) ? verts : nullptr, BF ? &adj : nullptr);
     const unsigned long long valid_mask = __builtin_amdgcn_ballot_w64(valid);
     if (valid_mask == 0ull) return;  // wave-uniform
+    if (BF) {
+        // The cell's boundary faces a ray can ENTER through leave a record for entry_raster_rec (device_types.hpp:
+        // BFaceRecord): the vertices and the face planes are in registers here, the raster would have to find them again
+        // through three dependent rounds of loads (face -> cell -> vertex ids -> coordinates).  One wavefront in sixteen
+        // has a boundary cell on the C3 grid.
+        const bool b_cell = valid && (adj.x <= -2 || adj.y <= -2 || adj.z <= -2 || adj.w <= -2);
+        if (__builtin_amdgcn_ballot_w64(b_cell) != 0ull && b_cell) {
+            const int nbv[4] = {adj.x, adj.y, adj.z, adj.w};
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                if (nbv[f] > -2) continue;
+                const FacePlane fp = face_plane(verts, f);
+                // walking from +z to -z a ray enters through faces the cell body lies below (upper faces); walking from -z
+                // to +z through the others; an edge-on face is entered by no ray
+                if (fp.kind == 0 || ((fp.kind > 0) != (g.bf_want_upper != 0))) continue;
+                constexpr int FV3[4][3] = {{0, 1, 2}, {0, 1, 3}, {0, 2, 3}, {1, 2, 3}};
+                const double* a = verts[FV3[f][0]];
+                const double* b = verts[FV3[f][1]];
+                const double* c = verts[FV3[f][2]];
+                BFaceRecord rec;
+                rec.ax = a[0], rec.ay = a[1], rec.bx = b[0], rec.by = b[1], rec.cx = c[0], rec.cy = c[1];
+                rec.x0 = verts[0][0], rec.y0 = verts[0][1];
+                rec.pc = fp.c, rec.pgx = fp.gx, rec.pgy = fp.gy;
+                rec.cell_word = static_cast<uint32_t>(cell) |
+                                (face_key_exponent(a[0], a[1], a[2], b[0], b[1], b[2], c[0], c[1], c[2], fp.gx, fp.gy, g.bf_key_slack) << kEntrySlackShift);
+                rec.seq = g.bf_seq;
+                g.bfrec[-nbv[f] - 2] = rec;
+            }
+        }
+    }
     if (SPLIT) {
         // "depth_split": the cells that straddle a cutting plane go on the list plane_raster works through (one
         // allocation per wavefront and plane; the list has room for every cell at every plane)
@@ -99,10 +130,22 @@ __device__ __forceinline__ void build_records_block(const GridView& g, double al
     }
 }
 
-template <bool SPLIT>
+template <bool SPLIT, bool BF>
 __global__ __launch_bounds__(256) void build_records(GridView g, double alpha_limit, int order) {
     __shared__ Q4 s_rec[4][64 * kRecPad];
-    build_records_block<SPLIT>(g, alpha_limit, order, blockIdx.x, s_rec);
+    build_records_block<SPLIT, BF>(g, alpha_limit, order, blockIdx.x, s_rec);
+}
+
+// entry_raster from the face records of build_records: one wavefront per boundary face, one scalar load of 96 bytes
+// instead of three dependent rounds of gathers; a face without a record of THIS frame (turned away from the rays,
+// edge-on, its cell outside this context's rows) costs that one load.
+__global__ __launch_bounds__(256) void entry_raster_rec(GridView g, RasterArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int64_t face_idx = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * 4u + (threadIdx.x >> 6)));
+    if (face_idx >= g.n_bfaces) return;
+    const BFaceRecord* __restrict__ rp = g.bfrec + face_idx;
+    if (rp->seq != g.bf_seq) return;
+    raster_face(A, lane, face_idx, rp->ax, rp->ay, rp->bx, rp->by, rp->cx, rp->cy, rp->x0, rp->y0, rp->pc, rp->pgx, rp->pgy, rp->cell_word);
 }
 
 __global__ __launch_bounds__(256) void entry_raster(GridView g, RasterArgs A) { entry_raster_block(g, A, blockIdx.x); }
@@ -119,7 +162,7 @@ __global__ __launch_bounds__(256) void setup_fused(GridView g, double alpha_limi
     if (raster)
         entry_raster_block(g, A, idx);
     else
-        build_records_block<false>(g, alpha_limit, order, idx, s_rec);
+        build_records_block<false, false>(g, alpha_limit, order, idx, s_rec);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -254,10 +297,14 @@ int64_t walk_tiles(const ImageParams& im) {
 void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, int order) {
     if (g.n_cells <= 0) return;
     const unsigned blocks = static_cast<unsigned>((g.n_cells + 255) / 256);
-    if (g.split.n_slabs > 1)
-        hipLaunchKernelGGL(build_records<true>, dim3(blocks), dim3(256), 0, s, g, alpha_limit, order);
+    if (g.split.n_slabs > 1 && g.bfrec)
+        hipLaunchKernelGGL((build_records<true, true>), dim3(blocks), dim3(256), 0, s, g, alpha_limit, order);
+    else if (g.split.n_slabs > 1)
+        hipLaunchKernelGGL((build_records<true, false>), dim3(blocks), dim3(256), 0, s, g, alpha_limit, order);
+    else if (g.bfrec)
+        hipLaunchKernelGGL((build_records<false, true>), dim3(blocks), dim3(256), 0, s, g, alpha_limit, order);
     else
-        hipLaunchKernelGGL(build_records<false>, dim3(blocks), dim3(256), 0, s, g, alpha_limit, order);
+        hipLaunchKernelGGL((build_records<false, false>), dim3(blocks), dim3(256), 0, s, g, alpha_limit, order);
 }
 
 void launch_entry_lists(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
@@ -266,7 +313,10 @@ void launch_entry_lists(hipStream_t s, const GridView& g, const double* Xtab, co
     if (g.n_bfaces <= 0) return;
     const unsigned blocks = static_cast<unsigned>((g.n_bfaces + 3) / 4);
     const RasterArgs A{Xtab, Ytab, im, head, first, pool, capacity, counters, sticky, want_upper, key_slack};
-    hipLaunchKernelGGL(entry_raster, dim3(blocks), dim3(256), 0, s, g, A);
+    if (g.bfrec)
+        hipLaunchKernelGGL(entry_raster_rec, dim3(blocks), dim3(256), 0, s, g, A);
+    else
+        hipLaunchKernelGGL(entry_raster, dim3(blocks), dim3(256), 0, s, g, A);
 }
 
 void launch_setup_fused(hipStream_t s, const GridView& g, double alpha_limit, int order, const double* Xtab, const double* Ytab,
