@@ -102,7 +102,7 @@ constexpr size_t kStageChunk = size_t{4} << 20;  // pinned staging for pageable 
 constexpr int kFrameSlots = 2;
 constexpr int kStickyWords = 3;   // entries without a pool slot, rays over the step bound, rays that skipped an entry
 constexpr int kStatusWords = 3;   // a frame's own walk_overflow, entry_overflow, overlap_rays (FrameCounters, shard 0)
-constexpr size_t kCountersBytes = sizeof(c5::FrameCounters) * c5::kCounterShards;  // device_types.hpp
+constexpr size_t kCountersBytes = sizeof(c5::FrameCounters) * c5::kCounterLines;  // the shards + DepthFitSums (device_types.hpp)
 
 // Everything one frame writes before its image: two slots, so that the per-view setup of frame
 // k + 1 (HBM-bound: transform, records, entry lists, solid mask) can run on the auxiliary stream
@@ -129,6 +129,7 @@ struct FrameSlot {
     uint64_t split_seq = 0;      // raster frames so far: stamp = seq % 15 + 1, counter half = seq & 1
     int setup_split = 1;         // slabs the slot's per-view data (plane cells) were built for ("view_cache")
     double setup_w[c5::kMaxSlabs + 1] = {};
+    double setup_g[2] = {0.0, 0.0};
     int64_t entry_capacity = 0;
     bool head_clean = false;  // the per-pixel entry heads are all zero (the walk kernels leave them so)
     c5::FrameCounters* host_counters = nullptr;  // pinned
@@ -169,6 +170,11 @@ struct c5_context {
     int split_auto_k = 1;   // what the last finished frame suggests (finish_frame)
     bool ray_depth_known = false;  // ... and the depths its rays ran between (walk coordinate)
     double ray_depth_lo = 0.0, ray_depth_hi = 0.0;
+    // ... and the planes fitted through where its (sampled) rays entered the grid and where they ended (DepthFitSums):
+    // common tilt (fit_gx, fit_gy) and the two planes' depths at x = y = 0 once that tilt is taken out
+    bool fit_known = false;
+    double fit_gx = 0.0, fit_gy = 0.0, fit_entry0 = 0.0, fit_exit0 = 0.0;
+    double split_tilt_x = 0.0, split_tilt_y = 0.0;  // "split_tilt_x" / "_y" (testing): the tilt of a FORCED split's planes
     double box_lo[3] = {0, 0, 0}, box_hi[3] = {0, 0, 0};  // the grid's bounding box in object space
     double alpha_floor = 0.0;  // smallest alpha of the grid that is >= DBL_EPSILON (+inf: none)
     int overlap_setup = 0;  // measured: 1.27 vs 1.26 ms/frame, the side stream buys nothing
@@ -601,6 +607,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev, c5::FrameCounters* own_count
     // "depth_split" (device_types.hpp: SplitParams): how many slabs of depth this frame's rays are cut into
     int split_k = 1;
     double split_w[c5::kMaxSlabs + 1] = {};
+    double split_g[2] = {0.0, 0.0};  // the planes' common tilt
     {
         const bool able = !bin_sort && !ctx->pipeline && !ctx->fuse_setup && !ctx->overlap_setup && ctx->order == 0 &&
                           ctx->tile_shape == 3 && ctx->xcd_mode == 2 && ctx->lds_stage == 2 && g.n_cells > 0 &&
@@ -626,6 +633,31 @@ int enqueue_frame(c5_context* ctx, float2* out_dev, c5::FrameCounters* own_count
             // that renders of different rows of one frame stay bit-equal)
             if (ctx->depth_split == 0 && ctx->ray_depth_known && ctx->ray_depth_lo >= z_lo && ctx->ray_depth_hi <= z_hi)
                 z_lo = ctx->ray_depth_lo, z_hi = ctx->ray_depth_hi;
+            // Planes of constant depth cut the rays of an oblique view at different fractions (the cube of the benchmark seen
+            // at -X 0.1 -Y 0.07: a ray's entry depth changes by 0.22 across the image, a fifth of its length - the longest
+            // third of a ray cut in three had 83 of its 183 steps).  With the planes fitted through the last frame's entries
+            // and ends at hand, the cutting planes take their mean tilt and divide the stretch between the two at the
+            // sample's centre: parallel planes, in order everywhere.  Quantised (2^-16, 2^-20 of the grid's size), so that
+            // the last bits of sums added in another order do not move them from frame to frame.
+            if (ctx->depth_split == 0 && ctx->fit_known) {
+                const double q_g = 0x1p-16, q_w = std::ldexp(std::fmax(ctx->grid_diagonal, 1e-300), -20);
+                split_g[0] = std::round(ctx->fit_gx / q_g) * q_g;
+                split_g[1] = std::round(ctx->fit_gy / q_g) * q_g;
+                z_lo = std::round(ctx->fit_entry0 / q_w) * q_w;
+                z_hi = std::round(ctx->fit_exit0 / q_w) * q_w;
+            } else if (ctx->depth_split >= 2 && (ctx->split_tilt_x != 0.0 || ctx->split_tilt_y != 0.0)) {
+                // (testing: a forced tilt; the bounding box's corners in the tilted coordinate)
+                split_g[0] = ctx->split_tilt_x, split_g[1] = ctx->split_tilt_y;
+                z_lo = INFINITY, z_hi = -INFINITY;
+                for (int corner = 0; corner < 8; ++corner) {
+                    double c[3] = {(corner & 1) ? ctx->box_hi[0] : ctx->box_lo[0], (corner & 2) ? ctx->box_hi[1] : ctx->box_lo[1],
+                                   (corner & 4) ? ctx->box_hi[2] : ctx->box_lo[2]};
+                    rotate_host(ctx->view, c);
+                    const double d = c[2] - split_g[0] * c[0] - split_g[1] * c[1];
+                    z_lo = std::fmin(z_lo, d);
+                    z_hi = std::fmax(z_hi, d);
+                }
+            }
             if (z_hi > z_lo && std::isfinite(z_hi - z_lo)) {
                 split_k = std::min(want, c5::kMaxSlabs);
                 split_w[0] = -DBL_MAX;
@@ -672,7 +704,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev, c5::FrameCounters* own_count
     const bool cacheable = ctx->view_cache && !ctx->pipeline && !bin_sort && !ctx->fuse_setup && !ctx->overlap_setup && g.n_cells > 0;
     const bool same_view = cacheable && fs.setup_epoch == ctx->setup_epoch && same_rotations(fs.setup_view, ctx->view) &&
                            fs.setup_limit == ctx->alpha_limit && fs.setup_order == ctx->order && fs.setup_split == split_k &&
-                           std::memcmp(fs.setup_w, split_w, sizeof split_w) == 0;
+                           std::memcmp(fs.setup_w, split_w, sizeof split_w) == 0 && std::memcmp(fs.setup_g, split_g, sizeof split_g) == 0;
     const bool reuse = same_view && fs.setup_kept;
     fs.setup_reused = reuse;
     fs.setup_epoch = cacheable ? ctx->setup_epoch : 0;
@@ -682,6 +714,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev, c5::FrameCounters* own_count
     fs.setup_kept = same_view;  // (this frame's walk leaves the heads in place)
     fs.setup_split = split_k;
     std::memcpy(fs.setup_w, split_w, sizeof split_w);
+    std::memcpy(fs.setup_g, split_g, sizeof split_g);
     c5::SplitParams sp{};
     if (split_k > 1) {
         if (!reuse) {
@@ -693,6 +726,8 @@ int enqueue_frame(c5_context* ctx, float2* out_dev, c5::FrameCounters* own_count
         sp.n_slabs = split_k;
         sp.stamp = static_cast<uint32_t>(fs.split_seq % 15) + 1u;
         std::memcpy(sp.w, split_w, sizeof split_w);
+        sp.gx = split_g[0];
+        sp.gy = split_g[1];
         sp.plane_cell = fs.plane_cell.as<uint32_t>();
         sp.plane_stride = padded;
         sp.straddle = fs.straddle.as<uint32_t>();
@@ -957,6 +992,47 @@ int finish_frame(c5_context* ctx) {
                 if (static_cast<double>(hc.ray_tiles) * (t * mean_over_max + 0.5) <= slots) k = t;
             k = std::min(k, static_cast<int>(static_cast<double>(hc.seg_max) / 56.0));
             k = std::max(1, k);
+        }
+        {   // the planes through the sampled rays' entries and ends: z ~ a + b x + c y by least squares, each; then the mean
+            // tilt, and what is left of either plane's depth at the origin once that tilt is taken out of its sample
+            const c5::DepthSamples& smp = *reinterpret_cast<const c5::DepthSamples*>(fs.host_counters + c5::kCounterShards);
+            struct { double entry[9], exit_[9]; } fit{};  // n, Sx, Sy, Sxx, Sxy, Syy, Sz, Sxz, Syz
+            {
+                const c5::ImageParams& im = ctx->im;  // (c5_set_image drains the ring before it changes it)
+                const int n_slots = std::min<int64_t>(c5::kFitSlots, static_cast<int64_t>(im.fit_cols) * ((im.res_y >> im.fit_shift) + 1));
+                const int mid = ((1 << im.fit_shift) - 1) >> 1;
+                for (int slot = 0; slot < n_slots; ++slot) {
+                    if (smp.entry_key[slot] == 0ull || smp.exit_key[slot] == 0ull) continue;
+                    const double x = im.x_min + im.step_x * (((slot % im.fit_cols) << im.fit_shift) + mid);
+                    const double y = im.y_min + im.step_y * (((slot / im.fit_cols) << im.fit_shift) + mid);
+                    const double z[2] = {c5::depth_of_key(smp.entry_key[slot]), c5::depth_of_key(smp.exit_key[slot])};
+                    double* const sums[2] = {fit.entry, fit.exit_};
+                    for (int t = 0; t < 2; ++t) {
+                        const double v[9] = {1.0, x, y, x * x, x * y, y * y, z[t], x * z[t], y * z[t]};
+                        for (int j = 0; j < 9; ++j) sums[t][j] += v[j];
+                    }
+                }
+            }
+            auto solve = [](const double* m, double out[3]) {  // normal equations, Cramer (3 x 3, well scaled: x, y ~ 1)
+                const double n = m[0], sx = m[1], sy = m[2], sxx = m[3], sxy = m[4], syy = m[5], sz = m[6], sxz = m[7], syz = m[8];
+                const double det = n * (sxx * syy - sxy * sxy) - sx * (sx * syy - sxy * sy) + sy * (sx * sxy - sxx * sy);
+                if (!(std::fabs(det) > 1e-12 * std::fabs(n * sxx * syy) && n >= 12.0)) return false;
+                out[0] = (sz * (sxx * syy - sxy * sxy) - sx * (sxz * syy - sxy * syz) + sy * (sxz * sxy - sxx * syz)) / det;
+                out[1] = (n * (sxz * syy - syz * sxy) - sz * (sx * syy - sxy * sy) + sy * (sx * syz - sxz * sy)) / det;
+                out[2] = (n * (sxx * syz - sxy * sxz) - sx * (sx * syz - sxz * sy) + sz * (sx * sxy - sxx * sy)) / det;
+                return std::isfinite(out[0]) && std::isfinite(out[1]) && std::isfinite(out[2]);
+            };
+            double pe[3], px[3];
+            ctx->fit_known = false;
+            if (solve(fit.entry, pe) && solve(fit.exit_, px)) {
+                const double gx = 0.5 * (pe[1] + px[1]), gy = 0.5 * (pe[2] + px[2]);
+                const double e0 = (fit.entry[6] - gx * fit.entry[1] - gy * fit.entry[2]) / fit.entry[0];
+                const double x0 = (fit.exit_[6] - gx * fit.exit_[1] - gy * fit.exit_[2]) / fit.exit_[0];
+                if (x0 > e0 && std::fabs(gx) < 64.0 && std::fabs(gy) < 64.0) {
+                    ctx->fit_known = true;
+                    ctx->fit_gx = gx, ctx->fit_gy = gy, ctx->fit_entry0 = e0, ctx->fit_exit0 = x0;
+                }
+            }
         }
         ctx->ray_depth_known = hc.exit_max_key != 0 && hc.entry_min_key != 0;
         if (ctx->ray_depth_known) {
@@ -1320,6 +1396,7 @@ int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int3
     ctx->alpha_floor = INFINITY;
     ctx->split_auto_k = 1;
     ctx->ray_depth_known = false;
+    ctx->fit_known = false;
     double edge2 = 0.0;
     for (int64_t c = 0; c < n_cells; ++c) {
         if (alpha[c] > ctx->alpha_top) ctx->alpha_top = alpha[c];  // (+inf counts: it is clamped to the limit; NaN never compares greater)
@@ -1472,6 +1549,10 @@ int c5_set_image(c5_context* ctx, int res_x, int res_y, const double* bounds4) {
     // plane.cpp:295-302
     im.step_x = (bounds4[0] - bounds4[1]) / (static_cast<double>(res_x) - 1.);
     im.step_y = (bounds4[2] - bounds4[3]) / (static_cast<double>(res_y) - 1.);
+    for (im.fit_shift = 3;; ++im.fit_shift) {  // the depth sample (DepthSamples): the finest raster of at most kFitSlots boxes
+        im.fit_cols = (res_x >> im.fit_shift) + 1;
+        if (static_cast<int64_t>(im.fit_cols) * ((res_y >> im.fit_shift) + 1) <= c5::kFitSlots) break;
+    }
     // plane.cpp:304-314: coordinates are running sums
     std::vector<double> X(static_cast<size_t>(res_x)), Y(static_cast<size_t>(res_y));
     double cx = bounds4[1];
@@ -1610,6 +1691,9 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
         for (Solid& so : ctx->solids) so.own_mask_ready = false, so.unchanged_frames = 0, so.seen_generation = ~uint64_t{0};
     } else if (n == "view_cache") {
         ctx->view_cache = static_cast<int>(value) != 0;
+    } else if (n == "split_tilt_x" || n == "split_tilt_y") {  // testing: tilt of a forced split's planes
+        if (!(std::fabs(value) < 64.0)) return fail(ctx, C5_ERR_INVALID, "split tilt out of range");
+        (n == "split_tilt_x" ? ctx->split_tilt_x : ctx->split_tilt_y) = value;
     } else if (n == "entry_records") {
         ctx->entry_records = static_cast<int>(value) != 0;
     } else if (n == "depth_split") {

@@ -124,7 +124,8 @@ constexpr int kStraddleCounterStride = 32;  // u32 words: one 128-byte line per 
 struct SplitParams {
     int32_t n_slabs;            // K; 0 / 1: rays are walked whole
     uint32_t stamp;             // 1..15: a plane_cell word is valid iff its bits 28-31 hold this (no clearing per frame)
-    double w[kMaxSlabs + 1];    // w[0] = -DBL_MAX, w[K] = +DBL_MAX
+    double w[kMaxSlabs + 1];    // w[0] = -DBL_MAX, w[K] = +DBL_MAX: the planes' depths at x = y = 0 ...
+    double gx, gy;              // ... and their common tilt: plane s at pixel (x, y) = w[s] + gx x + gy y (0, 0: planes of constant depth)
     uint32_t* plane_cell;       // [K - 1][plane_stride]
     int64_t plane_stride;       // pixels of the local image, padded
     uint32_t* straddle;         // kStraddleShards lists of (cell | (plane - 1) << 28), appended to by build_records
@@ -153,6 +154,7 @@ struct ImageParams {
     int32_t n_local_rows;     // rows rendered by this context
     int32_t tile_rows, rank, world;  // row tile t (counted from row_begin) belongs to rank t % world
     int32_t row_begin, row_count;    // only rows [row_begin, row_begin + row_count) are rendered at all
+    int32_t fit_shift, fit_cols;     // the depth sample (DepthSamples): one pixel per 2^shift x 2^shift box, fit_cols boxes per row
     double x_min, y_min;      // bounds[1], bounds[3]
     double step_x, step_y;    // plane.cpp:298-302
 };
@@ -189,6 +191,19 @@ struct alignas(128) FrameCounters {
     unsigned long long exit_max_key;
     unsigned long long entry_min_key;
 };
+// Behind the kCounterShards FrameCounters, 32 more 128-byte lines (cleared and copied to the host with them): a SAMPLE of
+// the frame's rays - the middle pixel of every 2^fit_shift x 2^fit_shift box of the full image, at most kFitSlots of them,
+// each with a slot of its own (plain stores: sums by atomicAdd serialise on their few addresses, 0.4 ms at 4800x3600) -
+// with the depth at which the ray enters the grid (entry_raster) and the depth at which it ends (walk), as depth_key()s
+// (0: none).  The host fits a plane through either set: "depth_split" 0 tilts the next frame's cutting planes with them, so
+// that an oblique view's rays are cut at equal fractions (c_api.hip, finish_frame).
+constexpr int kFitSlots = 256;
+struct alignas(128) DepthSamples {
+    unsigned long long entry_key[kFitSlots];
+    unsigned long long exit_key[kFitSlots];
+};
+constexpr int kCounterLines = kCounterShards + static_cast<int>(sizeof(DepthSamples) / 128);
+
 // monotone map double -> u64, never 0 for a finite value (0 = "none" after the per-frame clear)
 __host__ __device__ inline unsigned long long depth_key(double w) {
     union { double d; unsigned long long u; } v;
@@ -242,6 +257,12 @@ __host__ __device__ inline int global_row_of(const ImageParams& im, int lrow) {
     if (im.world == 1) return im.row_begin + lrow;
     const int ltile = lrow / im.tile_rows;
     return im.row_begin + (ltile * im.world + im.rank) * im.tile_rows + (lrow - ltile * im.tile_rows);
+}
+// the slot of the depth sample (DepthSamples) a pixel fills, or -1
+__host__ __device__ inline int fit_slot_of(const ImageParams& im, int col, int global_row) {
+    const int mask = (1 << im.fit_shift) - 1, mid = mask >> 1;
+    if ((col & mask) != mid || (global_row & mask) != mid || im.fit_cols <= 0) return -1;
+    return (global_row >> im.fit_shift) * im.fit_cols + (col >> im.fit_shift);
 }
 
 }  // namespace c5

@@ -35,7 +35,7 @@ __device__ __forceinline__ void rotate_point(const RotationList& R, double& x, d
     }
 }
 
-constexpr int64_t kCountersDwords = static_cast<int64_t>(sizeof(FrameCounters)) * kCounterShards / 4;
+constexpr int64_t kCountersDwords = static_cast<int64_t>(sizeof(FrameCounters)) * kCounterLines / 4;  // (the shards + DepthSamples)
 
 // SoA in -> SoA out (volume grid vertices): one thread per vertex, fully coalesced.
 __global__ __launch_bounds__(256) void transform_points_soa(const double* __restrict__ px,
@@ -535,10 +535,15 @@ __global__ __launch_bounds__(128) void clear_walk_counters(FrameCounters* __rest
             c.pool_used = raster_from[i].pool_used;
         }
     }
+    if (i < kFitSlots) {  // DepthSamples: the walk's start anew; the raster's stay (or come over with its other counters)
+        DepthSamples* fit = reinterpret_cast<DepthSamples*>(counters + kCounterShards);
+        fit->exit_key[i] = 0ull;
+        if (raster_from) fit->entry_key[i] = reinterpret_cast<const DepthSamples*>(raster_from + kCounterShards)->entry_key[i];
+    }
 }
 
 void launch_clear_walk_counters(hipStream_t s, FrameCounters* counters, uint32_t* sb, int n_sb, const FrameCounters* raster_from) {
-    const int n = std::max(kCounterShards, sb ? n_sb : 0);
+    const int n = std::max(std::max(kCounterShards, kFitSlots), sb ? n_sb : 0);
     hipLaunchKernelGGL(clear_walk_counters, dim3(static_cast<unsigned>((n + 127) / 128)), dim3(128), 0, s, counters, sb, n_sb,
                        raster_from == counters ? nullptr : raster_from);
 }

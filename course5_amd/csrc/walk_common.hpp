@@ -560,6 +560,7 @@ __device__ __forceinline__ void raster_face(const RasterArgs& A, int lane, int64
     }
     for (unsigned base = 0; base < n_box; base += 64u * kChunks) {
         bool in[kChunks];
+        int slot[kChunks];  // of the depth sample (DepthSamples), or -1
         size_t lp[kChunks];
         double z[kChunks];
         int old[kChunks];
@@ -567,6 +568,7 @@ __device__ __forceinline__ void raster_face(const RasterArgs& A, int lane, int64
         for (int k = 0; k < kChunks; ++k) {
             const unsigned idx = base + 64u * k + static_cast<unsigned>(lane);
             in[k] = false;
+            slot[k] = -1;
             lp[k] = 0;
             z[k] = 0.0;
             if (base + 64u * k >= n_box) continue;  // (wave-uniform: the permutes below want every lane)
@@ -608,6 +610,7 @@ __device__ __forceinline__ void raster_face(const RasterArgs& A, int lane, int64
                     in[k] = (e0 >= 0 && e1 >= 0 && e2 >= 0) || (e0 <= 0 && e1 <= 0 && e2 <= 0);
                     lp[k] = static_cast<size_t>(lrow) * im.res_x + col;
                     z[k] = pc + pgx * (x - x0) + pgy * (y - y0);
+                    slot[k] = in[k] ? fit_slot_of(im, col, global_row_of(im, lrow)) : -1;
                 }
             }
         }
@@ -621,6 +624,8 @@ __device__ __forceinline__ void raster_face(const RasterArgs& A, int lane, int64
                 e.cell = cell_word;
                 e.next = 0;
                 first[lp[k]] = e;
+                if (slot[k] >= 0)  // (in the walk coordinate)
+                    reinterpret_cast<DepthSamples*>(counters + kCounterShards)->entry_key[slot[k]] = depth_key(A.want_upper ? -z[k] : z[k]);
             }
             // further entries: one pool allocation per wavefront and chunk (same-address atomics serialise)
             const bool more = in[k] && old[k] > 0;

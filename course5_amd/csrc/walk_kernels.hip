@@ -86,14 +86,19 @@ __device__ __forceinline__ void build_records_block(const GridView& g, double al
     if (SPLIT) {
         // "depth_split": the cells that straddle a cutting plane go on the list plane_raster works through (one
         // allocation per wavefront and plane; the list has room for every cell at every plane)
+        // (a vertex's depth against the planes' common tilt: plane pl passes the cell if it lies between the least and the
+        // greatest of the four)
         double z_lo = 0.0, z_hi = 0.0, tol = 0.0;
         if (valid) {
-            z_lo = fmin(fmin(verts[0][2], verts[1][2]), fmin(verts[2][2], verts[3][2]));
-            z_hi = fmax(fmax(verts[0][2], verts[1][2]), fmax(verts[2][2], verts[3][2]));
-            double coord = 0.0;
+            double d[4], coord = 0.0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) coord = fmax(coord, fmax(fabs(verts[k][0]), fmax(fabs(verts[k][1]), fabs(verts[k][2]))));
-            tol = plane_tolerance(coord, z_hi - z_lo);
+            for (int k = 0; k < 4; ++k) {
+                d[k] = verts[k][2] - fma(g.split.gx, verts[k][0], g.split.gy * verts[k][1]);
+                coord = fmax(coord, fmax(fabs(verts[k][0]), fmax(fabs(verts[k][1]), fabs(verts[k][2]))));
+            }
+            z_lo = fmin(fmin(d[0], d[1]), fmin(d[2], d[3]));
+            z_hi = fmax(fmax(d[0], d[1]), fmax(d[2], d[3]));
+            tol = plane_tolerance(coord * (1.0 + fabs(g.split.gx) + fabs(g.split.gy)), z_hi - z_lo);
         }
         // The list is cut into kStraddleShards parts, each with its counter on a line of its own (thousands of wavefronts
         // adding to ONE word would serialise at ~10 ns each); a wavefront belongs to the part (its index mod 64), and a
@@ -231,11 +236,12 @@ __global__ __launch_bounds__(256) void plane_raster(GridView g, const double* __
             const double side = nx * (o[0] - a[0]) + ny * (o[1] - a[1]) + nz * (o[2] - a[2]);
             if (!(side != 0.0)) flat = true;  // (no volume, or NaN: claims nothing)
             if (side < 0.0) nx = -nx, ny = -ny, nz = -nz;
-            fa[f] = nx;
-            fb[f] = ny;
+            // the point of pixel (x, y) on plane pl is (x, y, w + gx x + gy y): s_f stays linear in x and y
+            fa[f] = fma(nz, g.split.gx, nx);
+            fb[f] = fma(nz, g.split.gy, ny);
             fc[f] = nz * (w - a[2]) - nx * a[0] - ny * a[1];
             // rounding of s_f at a pixel: a few ulps of the largest term
-            ft[f] = 32.0 * DBL_EPSILON * ((fabs(nx) + fabs(ny) + fabs(nz)) * coord);
+            ft[f] = 32.0 * DBL_EPSILON * ((fabs(nx) + fabs(ny) + fabs(nz) * (1.0 + fabs(g.split.gx) + fabs(g.split.gy))) * coord);
         }
         if (flat) continue;
         const double xmin = fmin(fmin(p[0][0], p[1][0]), fmin(p[2][0], p[3][0])), xmax = fmax(fmax(p[0][0], p[1][0]), fmax(p[2][0], p[3][0]));
@@ -678,7 +684,7 @@ using LdsInts = const __attribute__((address_space(3))) int*;
 // depth; a job leaves partial results and the tile's last job to arrive composes them.  ORDER 0, one wavefront per
 // workgroup.  Everything it adds is compiled out of the whole-ray instantiations.
 template <int TILE, int ORDER, bool DMA = false, int SLOTS = kStageSlots, bool SMALLEXP = false, bool SPLIT = false>
-__global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WALK_WAVES) void walk_composite_lds(WalkParams P) {
+__global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVES) : C5_WALK_WAVES) void walk_composite_lds(WalkParams P) {
     static_assert(!SPLIT || (ORDER == 0 && DMA && TileShape<TILE>::GX * TileShape<TILE>::GY == 1), "depth_split: reference order, LDS-DMA, one wavefront per workgroup");
     constexpr int kStageSlots = SLOTS;  // (shadows the namespace constant: everything below is per instantiation)
     using TS = TileShape<TILE>;
@@ -741,9 +747,10 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
         tx = within / BAND;
         if (ty >= tiles_y) return;
     }
-    // SPLIT: this job's slab of depth [w_lo, w_hi) (the first from -DBL_MAX, the last to +DBL_MAX)
-    const double w_lo = SPLIT ? P.split.w[slab] : -DBL_MAX;
-    const double w_hi = SPLIT ? P.split.w[slab + 1] : DBL_MAX;
+    // SPLIT: this job's slab of depth [w_lo, w_hi) at the lane's pixel (the first from -DBL_MAX, the last to +DBL_MAX; the
+    // planes share a tilt: device_types.hpp); w_lo is wanted at the start and at re-entries only and is worked out there
+    double w_hi = DBL_MAX;
+    auto slab_lo = [&](double px, double py) { return SPLIT ? P.split.w[slab] + fma(P.split.gx, px, P.split.gy * py) : -DBL_MAX; };
 
     // Registers are what caps the resident wavefronts here, so per-lane state the steps do not need
     // (pixel index, entry head, solid colour, s_cur) is NOT carried through the loop: it is recomputed
@@ -772,6 +779,7 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
 
     constexpr unsigned kOverflowBit = 0x80000000u;  // of n_seg: the ray hit the step bound
     constexpr unsigned kSkippedBit = 0x40000000u;   // of n_seg: the ray met an entry inside a stretch it had walked (next_entry)
+    constexpr unsigned kClippedBit = 0x20000000u;   // of n_seg (SPLIT): the ray goes on beyond the job's slab
     unsigned n_seg = 0;
     unsigned n_step_wave = 0;  // wave-uniform: lane-steps taken by the whole wavefront
     double tau = 0.0, I = 0.0, T = 1.0;
@@ -806,6 +814,8 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
             y = P.Ytab[global_row_of(im, pixel_lrow())];
             double w_cur = -DBL_MAX;
             bool skipped = false;
+            const double w_lo = slab_lo(x, y);
+            if (SPLIT) w_hi = P.split.w[slab + 1] + fma(P.split.gx, x, P.split.gy * y);
             if (SPLIT && slab > 0) {
                 // where is the ray at the cutting plane?  (plane_raster; a word of another frame: nowhere inside the grid)
                 const uint32_t pc = P.split.plane_cell[static_cast<size_t>(slab - 1) * P.split.plane_stride + lp];
@@ -1122,7 +1132,8 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
                 // (a clipped ray takes no further entry - own_hi = -DBL_MAX owns none - but the entries inside the stretch it
                 // has walked, up to the plane, are judged all the same)
                 nxt = next_entry<kUp>(P, lp, load_entry_head(P.entry_head + lp), w_cur, carry, key_taken,
-                                      clip ? w_hi : (has_exit ? sg.w_exit : -DBL_MAX), skipped, w_lo, clip ? -DBL_MAX : w_hi);
+                                      clip ? w_hi : (has_exit ? sg.w_exit : -DBL_MAX), skipped, slab_lo(x, y), clip ? -DBL_MAX : w_hi);
+                if (SPLIT && clip) n_seg |= kClippedBit;
                 if (skipped) n_seg |= kSkippedBit;
                 my_scur[lane] = w_cur;
             }
@@ -1184,6 +1195,17 @@ __global__ __launch_bounds__(256, DMA ? (SLOTS > 16 ? 7 : C5_DMA_WAVES) : C5_WAL
         }
     }
 
+    {   // the depth sample (DepthSamples): where the rays of the sampled pixels END - in this job, if it did not hand them on
+        const bool ended_here = (n_seg & ~(kOverflowBit | kSkippedBit | kClippedBit)) != 0u && (n_seg & kClippedBit) == 0u;
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int col = tx * TW + (wave % TS::GX) * TS::WW + (l % TS::WW), lrow = ty * TH + (wave / TS::GX) * TS::WH + (l / TS::WW);
+        if (ended_here && col < im.res_x && lrow < im.n_local_rows) {
+            const int slot = fit_slot_of(im, col, global_row_of(im, lrow));
+            if (slot >= 0) reinterpret_cast<DepthSamples*>(P.counters + kCounterShards)->exit_key[slot] = depth_key(carry);
+        }
+        n_seg &= ~kClippedBit;
+    }
     {   // ... and the deepest at which one of them ends (carry: where the ray left its last cell)
         double hi = (n_seg & ~(kOverflowBit | kSkippedBit)) ? carry : -DBL_MAX;
 #pragma unroll

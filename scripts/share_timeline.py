@@ -33,7 +33,7 @@ lines = [f"# {tag}: one GPU's share of the C3 frame (2400x1800), job by job; ker
 for rows in ((838, 124), (0, 514)):
     ctx.set_row_range(0, -1)
     ctx.set_row_range(*rows)
-    for k in (1, 2, 3, 4):
+    for k in (1, 2, 3, 4, 0):  # (0: the library's own choice - slabs from the statistics of the frame before, planes tilted to the view)
         ctx.set_option("depth_split", k)
         for _ in range(40):
             ctx.render()

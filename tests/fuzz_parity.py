@@ -94,8 +94,11 @@ def main():
         ctx.set_option("stage_slots", 21 if seed % 2 else 14)
         slabs = 2 + seed % 5
         ctx.set_option("depth_split", slabs)
+        tilt = np.random.default_rng(seed).uniform(-1.5, 1.5, 2) if seed % 3 else np.zeros(2)  # (planes tilted: 2 in 3)
+        ctx.set_option("split_tilt_x", float(tilt[0])); ctx.set_option("split_tilt_y", float(tilt[1]))
         img = ctx.render(); st = ctx.stats()
         ctx.set_option("depth_split", 0); ctx.set_option("stage_slots", 0)
+        ctx.set_option("split_tilt_x", 0.0); ctx.set_option("split_tilt_y", 0.0)
         a, b = img.astype(np.float64), ref["image"].astype(np.float64)
         tol = 1e-5 * np.maximum(np.abs(a), np.abs(b)) + 1e-6 * np.abs(b).max()
         n_bad = int((np.abs(a - b) > tol).sum())

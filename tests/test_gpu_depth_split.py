@@ -21,7 +21,7 @@ def _defaults(gpu_ctx):
     for k in range(8):
         gpu_ctx.set_solid(k, np.zeros((0, 12)))
     for name, v in (("tile", 3), ("integration", 0), ("lds_stage", 2), ("stage_slots", 0), ("algorithm", 0), ("xcd_mode", 2),
-                    ("entry_key", 1), ("view_cache", 1), ("depth_split", 0)):
+                    ("entry_key", 1), ("view_cache", 1), ("depth_split", 0), ("split_tilt_x", 0.0), ("split_tilt_y", 0.0)):
         gpu_ctx.set_option(name, v)
     gpu_ctx.set_row_tiles(0, 0, 1)
     gpu_ctx.set_row_range(0, -1)
@@ -30,6 +30,8 @@ def _defaults(gpu_ctx):
     gpu_ctx.set_option("depth_split", 0)
     gpu_ctx.set_option("stage_slots", 0)
     gpu_ctx.set_option("view_cache", 1)
+    gpu_ctx.set_option("split_tilt_x", 0.0)
+    gpu_ctx.set_option("split_tilt_y", 0.0)
 
 
 def _frame(ctx, rots, rx, ry, bounds=mg.REFERENCE_BOUNDS):
@@ -38,11 +40,15 @@ def _frame(ctx, rots, rx, ry, bounds=mg.REFERENCE_BOUNDS):
     return ctx.render(), ctx.stats()
 
 
+@pytest.mark.parametrize("tilt", [(0.0, 0.0), (0.31, -0.17), (-1.3, 0.8)], ids=lambda t: f"tilt{t[0]}_{t[1]}")
 @pytest.mark.parametrize("slabs", [2, 3, 4, 7])
 @pytest.mark.parametrize("path", golden_fixtures(), ids=lambda p: os.path.basename(p)[:-4])
-def test_golden_vectors_with_rays_cut_in_slabs(gpu_ctx, path, slabs):
+def test_golden_vectors_with_rays_cut_in_slabs(gpu_ctx, path, slabs, tilt):
     """Every golden fixture (G1, G2, G7 / G8 with hanging nodes, the non-convex ball) with the split forced: images
-    within the bar of the reference's, S and covered pixels equal; both slot counts of the walk."""
+    within the bar of the reference's, S and covered pixels equal; both slot counts of the walk.  The cutting planes
+    of constant depth, and tilted (depth - gx x - gy y constant: what the library fits by itself to an oblique view)."""
+    gpu_ctx.set_option("split_tilt_x", tilt[0])
+    gpu_ctx.set_option("split_tilt_y", tilt[1])
     fx = load_golden(path)
     if fx["name"].startswith("g4_"):
         pytest.skip("g4 holds alpha in [DBL_EPSILON, 1e-8): the reference's recurrence is its own cancellation noise there; "
@@ -58,7 +64,7 @@ def test_golden_vectors_with_rays_cut_in_slabs(gpu_ctx, path, slabs):
             _, whole = _frame(gpu_ctx, fx[f"rots{k}"], rx, ry, fx["bounds"])
             gpu_ctx.set_option("depth_split", slabs)
             img, st = _frame(gpu_ctx, fx[f"rots{k}"], rx, ry, fx["bounds"])
-            what = f"{fx['name']} view {k} slabs {slabs} slots {slots}"
+            what = f"{fx['name']} view {k} slabs {slabs} slots {slots} tilt {tilt}"
             r = assert_images_match(img[::stride, ::stride], fx[f"image{k}"], what)
             assert st["segments"] == int(fx[f"segments{k}"]), what
             assert st["covered_pixels"] == int(fx[f"covered{k}"]), what
@@ -141,6 +147,10 @@ def test_random_scenes_cut_in_slabs(gpu_ctx, oracle_port):
         gpu_ctx.set_alpha_limit(limit)
         slabs = 2 + seed % 5
         gpu_ctx.set_option("depth_split", slabs)
+        rng = np.random.default_rng(seed)
+        tilt = rng.uniform(-1.5, 1.5, 2) if seed % 3 else np.zeros(2)
+        gpu_ctx.set_option("split_tilt_x", float(tilt[0]))
+        gpu_ctx.set_option("split_tilt_y", float(tilt[1]))
         img, st = _frame(gpu_ctx, rots, res[0], res[1])
         assert st["segments"] == ref["segments"] and st["covered_pixels"] == ref["covered"], (seed, slabs)
         assert_images_match(img, ref["image"], f"seed {seed}, {slabs} slabs")
