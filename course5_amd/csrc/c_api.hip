@@ -506,7 +506,7 @@ int enqueue_bin_sort(c5_context* ctx, FrameSlot& fs, const c5::GridView& g, int 
     C5_HIP(ctx, hipMemcpyAsync(ctx->host_sticky, ctx->sticky.ptr, kStickyWords * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     C5_HIP(ctx, hipStreamSynchronize(s));
     ctx->counters_on_host = true;
-    fs.host_counters->segments = static_cast<unsigned long long>(total);
+    fs.host_counters->seg_tiles = static_cast<unsigned long long>(total);  // (fewer than 2^40: they were all allocated)
     if (ctx->pipeline) {  // keep the two-stream bookkeeping consistent
         C5_HIP(ctx, hipEventRecord(fs.setup_done, s));
         C5_HIP(ctx, hipStreamWaitEvent(main_s, fs.setup_done, 0));
@@ -924,19 +924,22 @@ int finish_frame(c5_context* ctx) {
     if (!ctx->frame_pending) return C5_OK;
     ctx->frame_pending = false;
     FrameSlot& fs = ctx->slots[ctx->last_slot];
-    c5::FrameCounters hc{};  // sum of the shards
+    struct {  // the shards' sums, the packed pairs taken apart (device_types.hpp: FrameCounters)
+        unsigned long long segments = 0, steps = 0, covered = 0, solid_pixels = 0, entries = 0, ray_tiles = 0, exit_max_key = 0, entry_min_key = 0;
+        unsigned walk_overflow = 0, entry_overflow = 0, odd_pixels = 0, pool_used = 0, seg_max = 0;
+    } hc;
     for (int k = 0; k < c5::kCounterShards; ++k) {
         const c5::FrameCounters& p = fs.host_counters[k];
-        hc.segments += p.segments;
-        hc.steps += p.steps;
-        hc.covered += p.covered;
-        hc.solid_pixels += p.solid_pixels;
-        hc.entries += p.entries;
+        hc.segments += p.seg_tiles & c5::kCounterLowMask;
+        hc.ray_tiles += p.seg_tiles >> c5::kCounterHighShift;
+        hc.steps += p.steps_cov & c5::kCounterLowMask;
+        hc.covered += p.steps_cov >> c5::kCounterHighShift;
+        hc.entries += p.ent_solid & c5::kCounterLowMask;
+        hc.solid_pixels += p.ent_solid >> c5::kCounterHighShift;
         hc.walk_overflow += p.walk_overflow;
         hc.entry_overflow += p.entry_overflow;
         hc.odd_pixels += p.odd_pixels;
         hc.pool_used += p.pool_used;
-        hc.ray_tiles += p.ray_tiles;
         hc.seg_max = std::max(hc.seg_max, p.seg_max);
         hc.exit_max_key = std::max(hc.exit_max_key, p.exit_max_key);
         hc.entry_min_key = std::max(hc.entry_min_key, p.entry_min_key);
@@ -944,14 +947,20 @@ int finish_frame(c5_context* ctx) {
     c5_stats& st = ctx->last;
     // The order the next frames' rows of super-blocks start in.  A frame with fewer wavefronts of rays than about two
     // rounds of the GPU's wavefront slots lasts as long as its longest wavefronts plus the time the dispatcher takes
-    // to reach them behind thousands of empty or short tiles: such frames start their rows dearest first (by this
-    // frame's cost per row, in eight classes of the dearest row's so that rows of about the same cost keep their
-    // image order: C2 ball 0.112 -> 0.098 ms).  Larger frames (several rounds of wavefronts) lose a little that way
-    // (C3 frame 0.540 -> 0.551 ms: every slot starts a full-length ray at once) and stay in image order.
+    // to reach them behind thousands of empty or short tiles, and ends on whatever started last: such frames start
+    // the rows with the LONGEST RAYS first (by this frame's longest ray per row - of one tile per super-block - in eight
+    // classes of the longest of all, so that rows of about the same length keep their image order).  Round 4 (profiles/
+    // experiments.md): the key used to be the row's SUM of segments, which sent a cut-off row of full-length rays at the
+    // lower edge of a share to the very end (the upper half of the C3 frame: 0.318 -> 0.347 ms with the order, 0.301 with
+    // this one; an eighth of the 4800x3600 frame at the image's edge 0.307 -> 0.247).  Larger frames (several rounds of
+    // wavefronts) lose a little (C3 frame 0.534 -> 0.542 ms) and stay in image order; so do frames of a few hundred
+    // wavefronts (C2 ball at 600x450: 0.106 -> 0.112).
     ctx->sb_order_key = -1;
     ctx->sb_order_n = 0;
-    constexpr unsigned long long kSmallFrameRays = 2ull * 256 * 28 * 64;  // two rounds of 7 wavefronts per SIMD
-    if (fs.sb_key >= 0 && ctx->host_sb && fs.sb_n > 1 && fs.sb_n <= c5::kMaxSbRows && hc.covered > 0 && hc.covered < kSmallFrameRays) {
+    constexpr unsigned long long kSmallFrameRays = 2ull * 256 * 32 * 64;  // two rounds of 8 wavefronts per SIMD
+    constexpr unsigned long long kTinyFrameRays = 100000;                  // ~1 500 wavefronts
+    if (fs.sb_key >= 0 && ctx->host_sb && fs.sb_n > 1 && fs.sb_n <= c5::kMaxSbRows &&
+        ((hc.covered >= kTinyFrameRays && hc.covered < kSmallFrameRays) || (hc.covered > 0 && ctx->cost_order == 2))) {
         const int n = fs.sb_n;
         uint32_t top = 0;
         for (int j = 0; j < n; ++j) top = std::max(top, ctx->host_sb[j]);
@@ -1679,7 +1688,7 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
     } else if (n == "overlap_setup") {
         ctx->overlap_setup = static_cast<int>(value) != 0;
     } else if (n == "cost_order") {
-        ctx->cost_order = static_cast<int>(value) != 0;
+        ctx->cost_order = static_cast<int>(value);  // (2: whatever the frame's size - experiments)
     } else if (n == "entry_key") {
         ctx->entry_key = static_cast<int>(value) != 0;
         ctx->overlap_seen = false;  // (with the testing value 0 an abutting entry can look like a skipped one: judge anew)

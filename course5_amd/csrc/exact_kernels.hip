@@ -410,8 +410,8 @@ __global__ __launch_bounds__(256) void resolve_pixels(GridView g, ImageParams im
         solid += __shfl_xor(solid, d);
     }
     if ((threadIdx.x & 63) == 0) {
-        if (covered) atomicAdd(&counters->covered, static_cast<unsigned long long>(covered));
-        if (solid) atomicAdd(&counters->solid_pixels, static_cast<unsigned long long>(solid));
+        if (covered) atomicAdd(&counters->steps_cov, static_cast<unsigned long long>(covered) << kCounterHighShift);
+        if (solid) atomicAdd(&counters->ent_solid, static_cast<unsigned long long>(solid) << kCounterHighShift);
     }
     (void)count0;
 }
@@ -518,15 +518,12 @@ __global__ __launch_bounds__(128) void clear_walk_counters(FrameCounters* __rest
     if (sb && i < n_sb) sb[i] = 0u;
     if (i < kCounterShards) {
         FrameCounters& c = counters[i];
-        c.segments = 0;
-        c.steps = 0;
-        c.covered = 0;
-        c.solid_pixels = 0;
-        c.entries = 0;
+        c.seg_tiles = 0;
+        c.steps_cov = 0;
+        c.ent_solid = 0;
         c.walk_overflow = 0;
         c.overlap_rays = 0;
         c.odd_pixels = 0;
-        c.ray_tiles = 0;
         c.seg_max = 0;
         c.exit_max_key = 0;
         c.entry_min_key = 0;

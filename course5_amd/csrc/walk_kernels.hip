@@ -562,12 +562,9 @@ __global__ __launch_bounds__(256) void walk_composite(WalkParams P) {
             atomicAdd(P.sticky + 2, s_skip);
         }
         FrameCounters* const fc = P.counters + ((blockIdx.x * 4u + static_cast<unsigned>(threadIdx.x >> 6)) % kCounterShards);
-        if (s_ent) atomicAdd(&fc->entries, static_cast<unsigned long long>(s_ent));
-        if (s_seg) atomicAdd(&fc->segments, static_cast<unsigned long long>(s_seg));
-        if (s_seg) atomicAdd(&fc->ray_tiles, 1u);
-        if (s_step) atomicAdd(&fc->steps, static_cast<unsigned long long>(s_step));
-        if (s_cov) atomicAdd(&fc->covered, static_cast<unsigned long long>(s_cov));
-        if (s_sol) atomicAdd(&fc->solid_pixels, static_cast<unsigned long long>(s_sol));
+        if (s_seg) atomicAdd(&fc->seg_tiles, static_cast<unsigned long long>(s_seg) | (1ull << kCounterHighShift));
+        if (s_step | s_cov) atomicAdd(&fc->steps_cov, static_cast<unsigned long long>(s_step) | (static_cast<unsigned long long>(s_cov) << kCounterHighShift));
+        if (s_ent | s_sol) atomicAdd(&fc->ent_solid, static_cast<unsigned long long>(s_ent) | (static_cast<unsigned long long>(s_sol) << kCounterHighShift));
         if (s_ovf) {  // (shard 0, beside entry_overflow: the two words a frame's status is read from; rare, never contended)
             atomicAdd(&P.counters->walk_overflow, s_ovf);
             atomicAdd(P.sticky + 1, s_ovf);
@@ -730,7 +727,7 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
         if (sb >= sbx_n * sby_n) return;
         int sby = sb / sbx_n;
         const int sbx = sb - sby * sbx_n;
-        if (P.n_sb_rows == sby_n) sby = static_cast<int>(P.sb_order[sby]);  // dearest rows first (kernel argument)
+        if (P.n_sb_rows == sby_n) sby = static_cast<int>(P.sb_order[sby]);  // rows with the longest rays first (kernel argument)
         ty = sby * S + within / S;
         tx = sbx * S + (within - (within / S) * S);
         if (tx >= tiles_x || ty >= tiles_y) return;
@@ -831,11 +828,13 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
     my_elect[kBuckets1 + 64 + lane] = 0;  // slot ids: always a valid cell id, whatever the slot's state
     // (recomputed where it is wanted: nothing to keep in a register across the loop)
     auto fc_job = [&]() { return P.counters + ((blockIdx.x * 4u + static_cast<unsigned>(wave)) % kCounterShards); };
+    // one tile in sixteen (the first of its super-block; 1 x 1 where the launch has no super-blocks) speaks for the estimates
+    const bool sampler = P.xcd_mode != 2 || ((tx % P.band_tiles) == 0 && (ty % P.band_tiles) == 0);
     {   // the shallowest depth at which a ray of this job starts (c_api.hip places the next frame's cutting planes by it)
         double lo = nb >= 0 ? carry : DBL_MAX;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) lo = fmin(lo, __shfl_xor(lo, d));
-        if (lane == 0 && lo < DBL_MAX) atomicMax(&fc_job()->entry_min_key, depth_key(-lo));
+        if (lane == 0 && lo < DBL_MAX && sampler) atomicMax(&fc_job()->entry_min_key, depth_key(-lo));
     }
 
     // contribution of the step whose record is being replaced (integrated while the next loads fly)
@@ -1210,7 +1209,7 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
         double hi = (n_seg & ~(kOverflowBit | kSkippedBit)) ? carry : -DBL_MAX;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) hi = fmax(hi, __shfl_xor(hi, d));
-        if (lane == 0 && hi > -DBL_MAX) atomicMax(&fc_job()->exit_max_key, depth_key(hi));
+        if (lane == 0 && hi > -DBL_MAX && sampler) atomicMax(&fc_job()->exit_max_key, depth_key(hi));
     }
     if (SPLIT) {
         // The job's partial results, indexed tile * 64 + lane (whole 512-byte rows per array and wavefront), then the
@@ -1234,7 +1233,7 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
         before = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(before)));
         if (before + 1u != K) {
             if (lane == 0 && n_step_wave)
-                atomicAdd(&(P.counters + ((blockIdx.x * 4u + static_cast<unsigned>(wave)) % kCounterShards))->steps,
+                atomicAdd(&(P.counters + ((blockIdx.x * 4u + static_cast<unsigned>(wave)) % kCounterShards))->steps_cov,
                           static_cast<unsigned long long>(n_step_wave));
             return;
         }
@@ -1300,17 +1299,18 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
             atomicAdd(P.sticky + 2, s_skip);
         }
         FrameCounters* const fc = fc_job();
-        if (s_seg && P.sb_cost && P.xcd_mode == 2) {  // what this wavefront cost, to its row of super-blocks
+        // The longest ray of this tile, to its row of super-blocks (the order the next frames' rows start in, c_api.hip) - from ONE
+        // tile per super-block only (its first: the one a cut-off super-block at the image's edge has too): every wavefront
+        // adding to its row's word put thousands of same-address atomics on a handful of words (a share of 248 rows has 8
+        // rows of super-blocks: walk 0.219 -> 0.231 ms; the C3 frame + 0.7 %).
+        if (s_seg && sampler) {
+            atomicMax(&fc->seg_max, s_longest);
             const int sb_row = ty / P.band_tiles;
-            if (sb_row < kMaxSbRows) atomicAdd(P.sb_cost + sb_row, s_seg);
+            if (P.sb_cost && P.xcd_mode == 2 && sb_row < kMaxSbRows) atomicMax(P.sb_cost + sb_row, s_longest);
         }
-        if (s_ent) atomicAdd(&fc->entries, static_cast<unsigned long long>(s_ent));
-        if (s_seg) atomicAdd(&fc->segments, static_cast<unsigned long long>(s_seg));
-        if (s_seg) atomicAdd(&fc->ray_tiles, 1u);
-        if (s_seg) atomicMax(&fc->seg_max, s_longest);
-        if (n_step_wave) atomicAdd(&fc->steps, static_cast<unsigned long long>(n_step_wave));
-        if (s_cov) atomicAdd(&fc->covered, static_cast<unsigned long long>(s_cov));
-        if (s_sol) atomicAdd(&fc->solid_pixels, static_cast<unsigned long long>(s_sol));
+        if (s_seg) atomicAdd(&fc->seg_tiles, static_cast<unsigned long long>(s_seg) | (1ull << kCounterHighShift));
+        if (n_step_wave | s_cov) atomicAdd(&fc->steps_cov, static_cast<unsigned long long>(n_step_wave) | (static_cast<unsigned long long>(s_cov) << kCounterHighShift));
+        if (s_ent | s_sol) atomicAdd(&fc->ent_solid, static_cast<unsigned long long>(s_ent) | (static_cast<unsigned long long>(s_sol) << kCounterHighShift));
         if (s_ovf) {  // (shard 0, beside entry_overflow: the two words a frame's status is read from; rare, never contended)
             atomicAdd(&P.counters->walk_overflow, s_ovf);
             atomicAdd(P.sticky + 1, s_ovf);

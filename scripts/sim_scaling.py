@@ -18,7 +18,7 @@ from course5_amd.build import kernel_source_hash  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
-base = 6.0  # bench.py --row-base-cost
+base = float(os.environ.get("C5_ROW_BASE_COST", "6.0"))  # bench.py --row-base-cost
 ctx = capi.Context(0)
 out_dev = torch.zeros((3600, 4800, 2), dtype=torch.float32, device="cuda:0")  # room for the largest frame
 ctx.set_option("view_cache", 0)  # a benchmark of identical frames: each one does its whole per-view setup
