@@ -90,7 +90,7 @@ def parse():
                    help="N > 1: contiguous cost-balanced row blocks (default: every block is received at its final offset "
                         "of rank 0's frame, no reassembly pass; every rank builds only the records its rays can reach) or "
                         "cyclic 16-row tiles (one gather of padded strips + a reassembly pass on rank 0)")
-    p.add_argument("--row-base-cost", type=float, default=6.0,
+    p.add_argument("--row-base-cost", type=float, default=3.0,
                    help="blocks: fixed cost per pixel in segment units added when balancing (measured: an empty "
                         "pixel costs about six segments)")
     return p.parse_args()
@@ -362,10 +362,31 @@ def main():
             if ctx.synchronize() == capi.C5_OK:
                 break
         costs = gather_row_costs(ctx.row_costs(), eq, rank, world, rdev)
-        blocks = sharding.balanced_blocks(costs, world, base_cost=rx * args.row_base_cost)
+        blocks = sharding.balanced_blocks(costs, world, base_cost=rx * args.row_base_cost, quantum=8)
         ctx.set_option("row_costs", 0)
         ctx.set_row_range(*blocks[rank])
         del probe
+        # ... and cut again, twice, by what the ranks TOOK for those blocks (GPU time of a frame, HIP events): the model
+        # misses what a segment costs where and what a share costs whatever its rows (sharding.time_weighted_costs;
+        # `course --devices` does the same with the times of its probe frames)
+        for _ in range(2):
+            buf = torch.zeros((ctx.local_rows, rx, 2), dtype=torch.float32, device=dev)
+            mine = 0.0
+            for k in range(12):
+                render(buf)
+                if ctx.synchronize() == capi.C5_OK and k >= 6:
+                    t = ctx.stats()["ms_total"]
+                    mine = t if mine == 0.0 else min(mine, t)
+            del buf
+            times = torch.zeros(world, dtype=torch.float64, device=rdev)
+            times[rank] = mine
+            dist.all_reduce(times)
+            times = [float(v) for v in times.cpu()]
+            again = sharding.balanced_blocks(sharding.time_weighted_costs(costs, blocks, times, base_cost=rx * args.row_base_cost), world, quantum=8)
+            if again == blocks or min(times) <= 0.0:
+                break
+            blocks = again
+            ctx.set_row_range(*blocks[rank])
         return blocks
 
     def measure(rx, ry, steps, warmup, split, steadying):

@@ -17,8 +17,9 @@
 namespace {
 constexpr int kTileRows = 16;  // one workgroup row of 8x8 wavefront tiles
 constexpr std::size_t kProbeEvery = 64;   // blocks layout: every so many frames the walk counts segments per row
-constexpr double kRowBaseCost = 6.0;      // per pixel, in segments: what a pixel costs whether or not it meets the grid
+constexpr double kRowBaseCost = 3.0;      // per pixel, in segments: what a pixel costs whether or not it meets the grid
                                           // (bench.py --row-base-cost, scripts/sim_scaling.py: the same figure)
+constexpr int kBlockQuantum = 8;           // rows: blocks are cut at multiples of the walk's tile height (row_blocks.hpp)
 constexpr double kRebalanceGain = 1.08;   // blocks move when the dearest block is this much above what new blocks promise
 
 void hip_check(hipError_t e, const char* what) {
@@ -546,12 +547,34 @@ void plane::read_row_costs() {
     }
     if (!complete) return;  // the next probe frame decides
     const double base = kRowBaseCost * static_cast<double>(_x);
-    const std::vector<std::pair<int, int>> want = balanced_row_blocks(_row_cost, static_cast<int>(_ctx.size()), base);
+    // What the devices TOOK for their blocks (GPU time of the last frame each has completed: the probe frame or one behind
+    // it, same layout) corrects the model block by block: a segment costs more in the tiles of an oblique face than in the
+    // grid's body, and a share costs something whatever its rows (row_blocks.hpp: time_weighted_row_costs).
+    std::vector<double> times(_ctx.size(), 0.0);
+    bool timed = true;
+    for (std::size_t r = 0; r < _ctx.size(); ++r) {
+        c5_stats st{};
+        int rc = c5_get_stats(_ctx[r], &st);
+        if (rc == C5_RETRY) {  // (settled by this very call: remembered for the frames in flight, as in stats())
+            _retry_seen[r] = 1;
+            rc = C5_OK;
+        }
+        check(rc, "c5_get_stats", r);
+        times[r] = static_cast<double>(st.ms_total);
+        if (!(times[r] > 0.0) && _blocks[r].second > 0) timed = false;
+    }
+    std::vector<double> cost(_row_cost.size());
+    if (timed) {
+        cost = time_weighted_row_costs(_row_cost, base, _blocks, times);
+    } else {
+        for (std::size_t k = 0; k < cost.size(); ++k) cost[k] = static_cast<double>(_row_cost[k]) + base;
+    }
+    const std::vector<std::pair<int, int>> want = balanced_row_blocks(cost, static_cast<int>(_ctx.size()), kBlockQuantum);
     auto dearest = [&](const std::vector<std::pair<int, int>>& blocks) {
         double top = 0.0;
         for (const auto& b : blocks) {
-            double c = base * b.second;
-            for (int k = 0; k < b.second; ++k) c += _row_cost[static_cast<std::size_t>(b.first + k)];
+            double c = 0.0;
+            for (int k = 0; k < b.second; ++k) c += cost[static_cast<std::size_t>(b.first + k)];
             top = std::max(top, c);
         }
         return top;

@@ -18,7 +18,7 @@ from course5_amd.build import kernel_source_hash  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
-base = float(os.environ.get("C5_ROW_BASE_COST", "6.0"))  # bench.py --row-base-cost
+base = float(os.environ.get("C5_ROW_BASE_COST", "3.0"))  # bench.py --row-base-cost
 ctx = capi.Context(0)
 out_dev = torch.zeros((3600, 4800, 2), dtype=torch.float32, device="cuda:0")  # room for the largest frame
 ctx.set_option("view_cache", 0)  # a benchmark of identical frames: each one does its whole per-view setup
@@ -68,11 +68,23 @@ for res in ((2400, 1800), (4800, 3600)):
     entry = {"full_ms": round(full["ms_total"], 4), "full_walk_ms": round(full["ms_walk"], 4), "full_wall_ms": round(full["wall_ms"], 4), "world": {}}
     print(f"{res[0]}x{res[1]}: full frame {full['ms_total']:.3f} ms (walk {full['ms_walk']:.3f})", flush=True)
     for world in (2, 4, 8):
-        blocks = sharding.balanced_blocks(costs, world, base_cost=res[0] * base)
+        blocks = sharding.balanced_blocks(costs, world, base_cost=res[0] * base, quantum=8)
         per = []
         for b, n in blocks:
             ctx.set_row_range(b, n)
             per.append(timed())
+        # ... and cut again by the TIMES just measured (what bench.py --gpus N and `course --devices` do with the times of a
+        # probe frame: sharding.time_weighted_costs), twice; the best layout is kept
+        for _ in range(2):
+            again = sharding.balanced_blocks(sharding.time_weighted_costs(costs, blocks, [p["ms_total"] for p in per], base_cost=res[0] * base), world, quantum=8)
+            if again == blocks:
+                break
+            per2 = []
+            for b, n in again:
+                ctx.set_row_range(b, n)
+                per2.append(timed())
+            if max(p["ms_total"] for p in per2) < max(p["ms_total"] for p in per):
+                blocks, per = again, per2
         ctx.set_row_range(0, -1)
         tot = [round(p["ms_total"], 4) for p in per]
         wall = [round(p["wall_ms"], 4) for p in per]

@@ -10,6 +10,7 @@
 //   host_san solids                         init_polar: Roche lobe + sphere, unique faces -> counts
 //   host_san oracle <scene.bin> <out.f32>   the CPU oracle on a dumped scene (see the pytest for the layout)
 //   host_san blocks <world> <base> <c0> <c1> ...  cost-balanced row blocks of the native multi-GPU host
+//   host_san wblocks <world> <base> <t0> .. <c0> <c1> ...  the same blocks cut again by the times t_k their devices took
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -29,6 +30,7 @@
 #include "cli.hpp"
 #include "config.hpp"
 #include "row_blocks.hpp"
+#include <cstdlib>
 #include "scene.hpp"
 #include "fast_deflate.hpp"
 #include "vtk_io.hpp"
@@ -238,7 +240,21 @@ int main(int argc, char** argv) try {
         if (argc < 5) throw std::runtime_error("blocks: world base costs...");
         std::vector<uint32_t> cost;
         for (int k = 4; k < argc; ++k) cost.push_back(static_cast<uint32_t>(std::strtoul(argv[k], nullptr, 10)));
-        for (const auto& b : balanced_row_blocks(cost, std::atoi(argv[2]), std::atof(argv[3]))) std::printf("%d %d\n", b.first, b.second);
+        const char* q = std::getenv("C5_BLOCK_QUANTUM");
+        for (const auto& b : balanced_row_blocks(cost, std::atoi(argv[2]), std::atof(argv[3]), q ? std::atoi(q) : 1)) std::printf("%d %d\n", b.first, b.second);
+        return 0;
+    }
+    if (mode == "wblocks") {  // blocks cut again by measured times: world base t0 .. t(world-1) costs...
+        if (argc < 5) throw std::runtime_error("wblocks: world base times... costs...");
+        const int world = std::atoi(argv[2]);
+        const double base = std::atof(argv[3]);
+        if (argc < 4 + world + world) throw std::runtime_error("wblocks: too few numbers");
+        std::vector<double> times;
+        for (int k = 0; k < world; ++k) times.push_back(std::atof(argv[4 + k]));
+        std::vector<uint32_t> cost;
+        for (int k = 4 + world; k < argc; ++k) cost.push_back(static_cast<uint32_t>(std::strtoul(argv[k], nullptr, 10)));
+        const auto first = balanced_row_blocks(cost, world, base);
+        for (const auto& b : balanced_row_blocks(time_weighted_row_costs(cost, base, first, times), world)) std::printf("%d %d\n", b.first, b.second);
         return 0;
     }
     if (mode == "oracle") {

@@ -33,8 +33,9 @@ def san(tmp_path_factory):
     if r.returncode != 0:
         pytest.skip("sanitizer build failed here: " + r.stderr[-400:])
 
-    def run(*args):
-        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", OMP_NUM_THREADS="4")
+    def run(*args, **extra_env):
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", OMP_NUM_THREADS="4",
+                   **{k: str(v) for k, v in extra_env.items()})
         p = subprocess.run([exe, *[str(a) for a in args]], capture_output=True, text=True, errors="replace", timeout=120, env=env)
         report = "Sanitizer" in p.stderr or "runtime error" in p.stderr or "ERROR: " in p.stderr
         assert not report, (args, p.stderr[-3000:])
@@ -194,5 +195,23 @@ def test_row_blocks_equal_the_python_partition(san):
         p = san("blocks", world, base, *[int(c) for c in cost])
         assert p.returncode == 0, p.stderr
         got = [tuple(int(v) for v in line.split()) for line in p.stdout.strip().splitlines()]
-        assert got == sharding.balanced_blocks(cost, world, base_cost=base), (trial, n, world, base)
+        first = sharding.balanced_blocks(cost, world, base_cost=base)
+        assert got == first, (trial, n, world, base)
+        # (cuts at multiples of the walk's tile height)
+        p = san("blocks", world, base, *[int(c) for c in cost], C5_BLOCK_QUANTUM=8)
+        assert p.returncode == 0, p.stderr
+        got = [tuple(int(v) for v in line.split()) for line in p.stdout.strip().splitlines()]
+        want = sharding.balanced_blocks(cost, world, base_cost=base, quantum=8)
+        assert got == want, (trial, n, world, base)
+        assert sum(k for _, k in want) == n and all(k >= 1 for _, k in want)
+        if n >= 16 * world:
+            assert all(b % 8 == 0 for b, _ in want), want
+        # ... and cut again by the times the devices took for those blocks (time_weighted_row_costs / time_weighted_costs)
+        times = [float(np.round(t, 4)) for t in rng.uniform(0.05, 0.5, world)]
+        if trial % 5 == 0:
+            times[0] = 0.0  # a device without a time keeps its model costs
+        p = san("wblocks", world, base, *times, *[int(c) for c in cost])
+        assert p.returncode == 0, p.stderr
+        got = [tuple(int(v) for v in line.split()) for line in p.stdout.strip().splitlines()]
+        assert got == sharding.balanced_blocks(sharding.time_weighted_costs(cost, first, times, base_cost=base), world), (trial, n, world, base, times)
     assert san("blocks", 5, 1.0, 1, 2, 3).returncode == 1  # more devices than rows: a message
