@@ -156,14 +156,17 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  0 disables).  Both agree to rounding wherever the reference's recurrence is
  *                  well conditioned (it is not for DBL_EPSILON <= alpha < ~1e-8).
  *   "depth_split"  0 (default): a frame whose rays do not fill the GPU's wavefront slots - a small image, one GPU's rows of
- *                  a frame - and are long enough is rendered with every ray cut at K - 1 planes of constant depth (K <= 4,
- *                  chosen from the statistics of the frame before): K jobs per 8x8 pixel tile walk the K parts at once and
+ *                  a frame - and are long enough is rendered with every ray cut at K - 1 parallel planes of depth (K <= 4,
+ *                  chosen from the statistics of the frame before, the planes tilted so that an oblique view's rays are cut
+ *                  at equal fractions: fitted to where a sample of that frame's rays entered the grid and where they
+ *                  ended): K jobs per 8x8 pixel tile walk the K parts at once and
  *                  the partial integrals are composed in depth order (tau = sum; I <- exp(-tauc_s) I + b_s: the recurrence
  *                  of line.cpp:206-225 is affine in I).  Same segment counts; I differs from the whole-ray walk in its
  *                  rounding ORDER only (~1e-16) - which is why a grid with a clamped alpha in [DBL_EPSILON, 1e-6), where
  *                  the reference's recurrence is dominated by its own cancellation error, is never cut.  1: never.
- *                  2..8: always that many slabs, with planes that depend on the view alone (renders of different rows of
- *                  one frame are bit-equal only at the same slab count).  Default tile shape, "lds_stage" 2,
+ *                  2..8: always that many slabs, with planes of constant depth that depend on the view alone (renders of
+ *                  different rows of one frame are bit-equal only at the same slab count; "split_tilt_x" / "split_tilt_y",
+ *                  testing: the planes' tilt, depth - tx x - ty y = const).  Default tile shape, "lds_stage" 2,
  *                  "integration" 0 and "xcd_mode" 2 only; whole rays otherwise.  DESIGN.md section 4.3.
  *   "algorithm"    0 (default for conforming grids): face-adjacency walk.  1: bin_sort_resolve, the
  *                  reference's own algorithm on the GPU (every face of every cell scan-converted onto
@@ -175,9 +178,10 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  cell record once, straight into LDS (global_load_lds_dwordx4), and its rays read it from there;
  *                  1: the same staged through vector registers (global_load + ds_write_b128; also what 2 falls
  *                  back to beyond 2^24 cells); 0: every lane loads its own record.  Same results, bit for bit.
- *   "cost_order"   1 (default): frames with fewer rays than about two rounds of the GPU's wavefront slots start the rows of
- *                  their image dearest first (by the cost per row of the last frame the caller waited for) instead
- *                  of top to bottom; 0: always top to bottom.  Same results.
+ *   "cost_order"   1 (default): frames with fewer rays than about two rounds of the GPU's wavefront slots (and more than ~1 500
+ *                  wavefronts) start the rows of their image that hold the LONGEST rays first (by the last frame the caller
+ *                  waited for) instead of top to bottom: a launch ends on whatever started last; 0: always top to bottom;
+ *                  2: that order whatever the frame's size (experiments).  Same results.
  *   "stage_slots"  "lds_stage" 1 / 2: distinct cells staged per wavefront and step (LDS-DMA passes of seven).  0 (default): 21
  *                  when the frame before had fewer than 120 ray-cell segments per cell (pixels coarse against the cells:
  *                  more distinct cells per 8x8 tile), else 14 (one more wavefront per SIMD); 14 / 21: fixed.  Same results
