@@ -187,8 +187,8 @@ struct alignas(128) FrameCounters {
                                   // components interpenetrate there (walk_common.hpp: next_entry) - not a grid a walk can render
     unsigned int odd_pixels;  // bin_sort_resolve: (pixel, cell) pairs with an odd number of covering faces
     unsigned int pool_used;   // per shard: slots asked of this shard's part of the overflow pool (may exceed the part)
-    // from ONE tile in sixteen (the first of every 4 x 4 super-block; what they feed are estimates):
     unsigned int seg_max;     // most segments of any ray (per job of a cut ray: of any part)
+    // from ONE tile in sixteen (the first of every 4 x 4 super-block; what they feed are estimates):
     // the depths between which this frame's rays ran, as keys that atomicMax orders (0: no ray): depth_key() of the deepest
     // exit, and of the NEGATED shallowest entry ("depth_split" 0 places the next frame's cutting planes between them)
     unsigned long long exit_max_key;

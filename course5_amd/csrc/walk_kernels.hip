@@ -1303,8 +1303,8 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
         // tile per super-block only (its first: the one a cut-off super-block at the image's edge has too): every wavefront
         // adding to its row's word put thousands of same-address atomics on a handful of words (a share of 248 rows has 8
         // rows of super-blocks: walk 0.219 -> 0.231 ms; the C3 frame + 0.7 %).
+        if (s_seg) atomicMax(&fc->seg_max, s_longest);  // (exact: "depth_split" 0 decides by it, and the decision has a threshold)
         if (s_seg && sampler) {
-            atomicMax(&fc->seg_max, s_longest);
             const int sb_row = ty / P.band_tiles;
             if (P.sb_cost && P.xcd_mode == 2 && sb_row < kMaxSbRows) atomicMax(P.sb_cost + sb_row, s_longest);
         }
