@@ -131,6 +131,12 @@ struct FrameSlot {
     double setup_w[c5::kMaxSlabs + 1] = {};
     double setup_g[2] = {0.0, 0.0};
     int64_t entry_capacity = 0;
+    // which 8x8 tiles hold an entry (walk_common.hpp: RasterArgs::tile_flag): a word per tile = the number of the raster run
+    // that found one there
+    DeviceBuffer tile_flag;
+    uint32_t flag_seq = 0;
+    int64_t flag_tiles = 0;
+    bool flags_valid = false;  // the slot's entry lists were built by a raster that kept them
     bool head_clean = false;  // the per-pixel entry heads are all zero (the walk kernels leave them so)
     c5::FrameCounters* host_counters = nullptr;  // pinned
     hipEvent_t setup_done = nullptr, walk_done = nullptr;
@@ -153,6 +159,7 @@ struct c5_context {
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     int fuse_setup = 0;     // build_records + entry_raster as one launch of interleaved workgroups: measured 0.119 ms against
                             // 0.047 + 0.047 ms for the two launches on the C3 frame (the raster inherits the records' 49 KB of LDS)
+    int tile_flags = 1;     // "tile_flags": the raster marks the tiles that hold an entry, the walk looks there first (enqueue_frame)
     int cost_order = 1;     // "cost_order": rows of super-blocks start dearest first (by the last frame the host waited for)
     uint8_t sb_order[128] = {};
     long long sb_order_key = -1;
@@ -794,6 +801,27 @@ int enqueue_frame(c5_context* ctx, float2* out_dev, c5::FrameCounters* own_count
     // boundary entries: one raster pass (per-pixel count + first entry + overflow chain)
     if (!fs.head_clean && !reuse) C5_HIP(ctx, hipMemsetAsync(fs.head.ptr, 0, static_cast<size_t>(padded) * sizeof(c5::EntryHead), e));
     fs.head_clean = false;
+    // ... and a mark on every 8x8 tile that holds one ("tile_flags"; the default tile shape's tiling; not with "fuse_setup")
+    uint32_t* tile_flag = nullptr;
+    if (!reuse) {
+        fs.flags_valid = false;
+        if (ctx->tile_flags && ctx->tile_shape == 3 && ctx->lds_stage && !fused && g.n_cells > 0 && g.n_bfaces > 0) {
+            const int64_t tiles = c5::walk_tiles(im);
+            if (fs.flag_tiles != tiles || !fs.tile_flag.ptr) {
+                C5_HIP(ctx, fs.tile_flag.ensure(static_cast<size_t>(tiles) * sizeof(uint32_t)));
+                C5_HIP(ctx, hipMemsetAsync(fs.tile_flag.ptr, 0, static_cast<size_t>(tiles) * sizeof(uint32_t), e));
+                fs.flag_tiles = tiles;
+                fs.flag_seq = 0;
+            }
+            fs.flag_seq += 1;
+            if (fs.flag_seq == 0) {  // (4 billion raster runs on: no old mark may look current)
+                C5_HIP(ctx, hipMemsetAsync(fs.tile_flag.ptr, 0, static_cast<size_t>(tiles) * sizeof(uint32_t), e));
+                fs.flag_seq = 1;
+            }
+            tile_flag = fs.tile_flag.as<uint32_t>();
+            fs.flags_valid = true;
+        }
+    }
     if (fused) {
         // records and entry lists as ONE launch of interleaved workgroups ("fuse_setup"; ms_records then holds the
         // time of both and ms_entries is zero)
@@ -804,7 +832,7 @@ int enqueue_frame(c5_context* ctx, float2* out_dev, c5::FrameCounters* own_count
     } else if (g.n_cells > 0 && !reuse) {
         c5::launch_entry_lists(e, g, ctx->xtab.as<double>(), ctx->ytab.as<double>(), im, fs.head.as<c5::EntryHead>(),
                                fs.first.as<c5::Entry>(), fs.pool.as<c5::Entry>(), fs.entry_capacity, counters,
-                               ctx->sticky.as<unsigned>(), ctx->order != 0, key_slack);
+                               ctx->sticky.as<unsigned>(), ctx->order != 0, key_slack, tile_flag, fs.flag_seq);
     }
     C5_HIP(ctx, mark(3, e));
     // (a9) solids
@@ -842,6 +870,9 @@ int enqueue_frame(c5_context* ctx, float2* out_dev, c5::FrameCounters* own_count
     // walk_composite_lds addresses the records by 32-bit byte offsets: n_cells * 128 must fit
     wp.lds_stage = (ctx->lds_stage && ctx->n_cells < (int64_t{1} << 25)) ? ctx->lds_stage : 0;
     wp.counters = counters;
+    // (a pixel a solid covers is written by its wavefront whether or not the grid is there: with solids every tile is read)
+    wp.tile_flag = (fs.flags_valid && !any_solid && ctx->tile_flags) ? fs.tile_flag.as<uint32_t>() : nullptr;
+    wp.tile_stamp = fs.flag_seq;
     {   // every exp argument of this grid within (-1/8, 0]?  alpha_c <= min(limit, largest alpha), chord <= longest edge
         double a_max = std::fmin(ctx->alpha_top, ctx->alpha_limit);
         if (!(a_max >= 0.0)) a_max = ctx->alpha_top;  // (a NaN limit clamps nothing: line.cpp:216-218)
@@ -1687,6 +1718,8 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
         ctx->fuse_setup = static_cast<int>(value) != 0;
     } else if (n == "overlap_setup") {
         ctx->overlap_setup = static_cast<int>(value) != 0;
+    } else if (n == "tile_flags") {
+        ctx->tile_flags = static_cast<int>(value) != 0;
     } else if (n == "cost_order") {
         ctx->cost_order = static_cast<int>(value);  // (2: whatever the frame's size - experiments)
     } else if (n == "entry_key") {

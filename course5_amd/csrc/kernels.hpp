@@ -52,6 +52,9 @@ struct WalkParams {
     int32_t lds_pad;            // tuning: extra dynamic LDS per workgroup (bytes) to cap the resident wavefronts
     int32_t order;              // 0: back to front in the reference's arithmetic; 1: front to back + early-out
     FrameCounters* counters;
+    // tiles that hold an entry carry tile_stamp (walk_common.hpp: RasterArgs::tile_flag); nullptr: every tile reads its heads
+    const uint32_t* tile_flag;
+    uint32_t tile_stamp;
     // 1: no step of this grid can give exp an argument beyond -1/8, whatever the view: min(alpha limit, largest alpha)
     // times the longest edge of any cell stays below it (c_api.hip).  The walk then runs the instantiation that holds
     // only the short exp series — neither the wave-wide test of the argument per step nor the general exp's code
@@ -115,7 +118,8 @@ void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, 
 // (g.bfrec set: from the face records build_records left - entry_raster_rec; else every face finds its own vertices)
 void launch_entry_lists(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
                         const ImageParams& im, EntryHead* head, Entry* first, Entry* pool, int64_t capacity,
-                        FrameCounters* counters, unsigned* sticky, int want_upper, double key_slack);
+                        FrameCounters* counters, unsigned* sticky, int want_upper, double key_slack,
+                        uint32_t* tile_flag = nullptr, uint32_t tile_stamp = 0);
 // build_records and entry_raster as one launch of interleaved workgroups
 void launch_setup_fused(hipStream_t s, const GridView& g, double alpha_limit, int order, const double* Xtab, const double* Ytab,
                         const ImageParams& im, EntryHead* head, Entry* first, Entry* pool, int64_t capacity,

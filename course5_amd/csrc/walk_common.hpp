@@ -342,16 +342,18 @@ __device__ __forceinline__ EntryHead load_entry_head(const EntryHead* p) {
 // jobs of a ray take every entry once (device_types.hpp: SplitParams; whole rays: -DBL_MAX, DBL_MAX); entries below
 // own_lo belong to the stretch of a job further down and are not judged here.
 template <bool kUp>
+// has_pre: the pixel's first entry (pre_z, pre_cell) was loaded by the caller ahead of time (the walk's start: beside the
+// entry head; by value - a pointer to a local would put it in scratch)
 __device__ __forceinline__ int next_entry(const WalkParams& P, size_t lp, EntryHead h, double& w_cur, double& w_entry,
                                           double key_taken, double stretch_hi, bool& skipped, double own_lo = -DBL_MAX,
-                                          double own_hi = DBL_MAX) {
+                                          double own_hi = DBL_MAX, bool has_pre = false, double pre_z = 0.0, uint32_t pre_cell = 0u) {
     double key_best = DBL_MAX;
     int cell = -1;
     const Entry* e = P.entry_first + lp;
     int hop = h.chain;
     for (int k = 0; k < h.count; ++k) {  // bounded by the count: a chain cut short by a pool overflow ends at hop 0
-        const double z = e->z;
-        const uint32_t word = e->cell;
+        const double z = (has_pre && k == 0) ? pre_z : e->z;
+        const uint32_t word = (has_pre && k == 0) ? pre_cell : e->cell;
         const double we = kUp ? z : -z;
         const double slack = ldexp(P.key_slack, static_cast<int>(word >> kEntrySlackShift));
         const double key = we + slack;
@@ -430,6 +432,12 @@ struct RasterArgs {
     unsigned* sticky;
     int want_upper;
     double key_slack;  // the frame's uniform entry-key slack (entry_key_exponent's base; <= 0: none)
+    // Which 8x8 pixel tiles (counted from the context's first row) hold an entry at all: a tile's word = tile_stamp.  The walk
+    // asks for it first - one scalar load - and a wavefront whose tile has none stores its zeros without reading 64 entry
+    // heads; one that has asks for heads, first entries and coordinates in ONE round of loads (walk_kernels.hip).  nullptr: not kept.
+    uint32_t* tile_flag;
+    uint32_t tile_stamp;
+    int32_t tile_cols;  // tiles per row of tiles
 };
 
 __device__ __forceinline__ void raster_face(const RasterArgs& A, int lane, int64_t face_idx, double ax, double ay, double bx, double by,
@@ -528,6 +536,16 @@ __device__ __forceinline__ void raster_face(const RasterArgs& A, int lane, int64
     if (lr1 < lr0) return;
     const unsigned bw = static_cast<unsigned>(c1 - c0 + 1);
     const unsigned n_box = bw * static_cast<unsigned>(lr1 - lr0 + 1);  // <= pixels of the image: fits 32 bits
+    if (A.tile_flag) {
+        // every 8x8 tile the face's BOX meets is marked (a superset of the tiles that get an entry: a marked tile without one
+        // is read and found empty, an unmarked one is never read) - one store per face and lane, not one per pixel
+        const int tx0 = c0 >> 3, ty0 = lr0 >> 3;
+        const unsigned ntx = static_cast<unsigned>((c1 >> 3) - tx0 + 1), n_t = ntx * static_cast<unsigned>((lr1 >> 3) - ty0 + 1);
+        for (unsigned t = static_cast<unsigned>(lane); t < n_t; t += 64u) {
+            const unsigned r = t / ntx;
+            A.tile_flag[static_cast<size_t>(ty0 + static_cast<int>(r)) * A.tile_cols + tx0 + static_cast<int>(t - r * ntx)] = A.tile_stamp;
+        }
+    }
 
     // The raster is bound by vector instructions (the box of a face holds 2.5x the pixels of the face), so
     // the per-pixel work is kept small: the three edge functions as planes about vertex a (two fused
@@ -611,6 +629,7 @@ __device__ __forceinline__ void raster_face(const RasterArgs& A, int lane, int64
                     lp[k] = static_cast<size_t>(lrow) * im.res_x + col;
                     z[k] = pc + pgx * (x - x0) + pgy * (y - y0);
                     slot[k] = in[k] ? fit_slot_of(im, col, global_row_of(im, lrow)) : -1;
+
                 }
             }
         }

@@ -315,10 +315,12 @@ void launch_build_records(hipStream_t s, const GridView& g, double alpha_limit, 
 
 void launch_entry_lists(hipStream_t s, const GridView& g, const double* Xtab, const double* Ytab,
                         const ImageParams& im, EntryHead* head, Entry* first, Entry* pool, int64_t capacity,
-                        FrameCounters* counters, unsigned* sticky, int want_upper, double key_slack) {
+                        FrameCounters* counters, unsigned* sticky, int want_upper, double key_slack, uint32_t* tile_flag,
+                        uint32_t tile_stamp) {
     if (g.n_bfaces <= 0) return;
     const unsigned blocks = static_cast<unsigned>((g.n_bfaces + 3) / 4);
-    const RasterArgs A{Xtab, Ytab, im, head, first, pool, capacity, counters, sticky, want_upper, key_slack};
+    const RasterArgs A{Xtab, Ytab, im, head, first, pool, capacity, counters, sticky, want_upper, key_slack, tile_flag, tile_stamp,
+                       (im.res_x + 7) / 8};
     if (g.bfrec)
         hipLaunchKernelGGL(entry_raster_rec, dim3(blocks), dim3(256), 0, s, g, A);
     else
@@ -331,7 +333,7 @@ void launch_setup_fused(hipStream_t s, const GridView& g, double alpha_limit, in
     const unsigned n_rec = g.n_cells > 0 ? static_cast<unsigned>((g.n_cells + 255) / 256) : 0u;
     const unsigned n_ras = g.n_bfaces > 0 ? static_cast<unsigned>((g.n_bfaces + 3) / 4) : 0u;
     if (n_rec + n_ras == 0u) return;
-    const RasterArgs A{Xtab, Ytab, im, head, first, pool, capacity, counters, sticky, want_upper, key_slack};
+    const RasterArgs A{Xtab, Ytab, im, head, first, pool, capacity, counters, sticky, want_upper, key_slack, nullptr, 0u, 0};
     hipLaunchKernelGGL(setup_fused, dim3(n_rec + n_ras), dim3(256), 0, s, g, alpha_limit, order, n_rec, n_ras, A);
 }
 
@@ -792,11 +794,28 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
         size_t lp = 0;
         uint32_t mv = 0;
         EntryHead ent{0, 0};
+        // (round 4) The raster marks the tiles that hold an entry (RasterArgs::tile_flag).  One scalar load says whether this
+        // one does: if not, the zeros are stored without reading 64 entry heads; if so, heads, first entries and pixel
+        // coordinates are asked for in ONE round of loads instead of two dependent ones.  (Default tile shape; no solids.)
+        const bool flagged = (TILE == 3) && P.tile_flag != nullptr;
+        bool tile_has_entries = true;
+        if (flagged) tile_has_entries = P.tile_flag[static_cast<size_t>(ty) * tiles_x + tx] == P.tile_stamp;  // (uniform address)
+        double first_z = 0.0;
+        uint32_t first_cell = 0u;
         if (in_image) {
             lp = pixel_index();
             mv = P.mask ? P.mask[lp] : 0u;
-            // touched once per frame: keep them from displacing the cell records in L2 / Infinity Cache
-            ent = load_entry_head(P.entry_head + lp);
+            if (tile_has_entries) {
+                // touched once per frame: keep them from displacing the cell records in L2 / Infinity Cache
+                ent = load_entry_head(P.entry_head + lp);
+                if (flagged) {
+                    const Entry first_ahead = P.entry_first[lp];
+                    first_z = first_ahead.z;
+                    first_cell = first_ahead.cell;
+                    x = P.Xtab[pixel_col()];
+                    y = P.Ytab[global_row_of(im, pixel_lrow())];
+                }
+            }
         }
         if (__builtin_amdgcn_ballot_w64(mv != 0u || ent.count != 0) == 0ull) {
             // (SPLIT: every job of the tile comes to the same verdict; the first one writes the zeros)
@@ -807,8 +826,10 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
             return;
         }
         if (in_image && !mv) {  // (a solid-marked pixel is written at the end, without a walk)
-            x = P.Xtab[pixel_col()];
-            y = P.Ytab[global_row_of(im, pixel_lrow())];
+            if (!flagged) {
+                x = P.Xtab[pixel_col()];
+                y = P.Ytab[global_row_of(im, pixel_lrow())];
+            }
             double w_cur = -DBL_MAX;
             bool skipped = false;
             const double w_lo = slab_lo(x, y);
@@ -821,7 +842,8 @@ __global__ __launch_bounds__(256, DMA ? ((SLOTS > 16 || SPLIT) ? 7 : C5_DMA_WAVE
                     carry = w_lo;
                 }
             }
-            if (nb < 0 && ent.count > 0) nb = next_entry<kUp>(P, lp, ent, w_cur, carry, -DBL_MAX, -DBL_MAX, skipped, w_lo, w_hi);
+            if (nb < 0 && ent.count > 0)
+                nb = next_entry<kUp>(P, lp, ent, w_cur, carry, -DBL_MAX, -DBL_MAX, skipped, w_lo, w_hi, flagged, first_z, first_cell);
             my_scur[lane] = w_cur;  // the key of the entry taken (-DBL_MAX: started from a plane)
         }
     }

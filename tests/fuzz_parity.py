@@ -64,6 +64,15 @@ def main():
         if k % 50 == 0:
             print(f"... scene {k} of {n_scenes}, {bad} mismatching renders so far", flush=True)
         xyz, cells, alpha, q, rots, res, limit = scene(seed)
+        # A grid that reaches the last pixel column / row of the image is outside the contract: the reference clamps what
+        # lies beyond a border into the border pixels (plane.cpp:194-212 - or aborts, plane.cpp:39-41), the walk renders what
+        # is inside (tests/test_gpu_edges.py has those cases on purpose).  One scene in ~700 does.
+        v = o.rotate_points(xyz, rots)
+        bx = mg.REFERENCE_BOUNDS
+        px, py = (bx[0] - bx[1]) / (res[0] - 1), (bx[2] - bx[3]) / (res[1] - 1)
+        if v[:, 0].min() < bx[1] + px or v[:, 0].max() > bx[0] - px or v[:, 1].min() < bx[3] + py or v[:, 1].max() > bx[2] - py:
+            print(f"seed {seed}: the grid reaches the image's border - outside the contract, skipped")
+            continue
         try:
             ref = o.render(xyz, cells, alpha, q, rots, res[0], res[1], mg.REFERENCE_BOUNDS, alpha_limit=limit, threads=8)
         except RuntimeError as e:
