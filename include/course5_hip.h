@@ -182,6 +182,9 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  wavefronts) start the rows of their image that hold the LONGEST rays first (by the last frame the caller
  *                  waited for) instead of top to bottom: a launch ends on whatever started last; 0: always top to bottom;
  *                  2: that order whatever the frame's size (experiments).  Same results.
+ *   "tile_flags"   1 (default): the entry raster marks the 8x8 pixel tiles a boundary face's box meets, and a wavefront of the
+ *                  walk looks at its tile's mark before anything else (default tile shape, no solids); 0: every wavefront
+ *                  reads its pixels' entry heads.  Same results.
  *   "stage_slots"  "lds_stage" 1 / 2: distinct cells staged per wavefront and step (LDS-DMA passes of seven).  0 (default): 21
  *                  when the frame before had fewer than 120 ray-cell segments per cell (pixels coarse against the cells:
  *                  more distinct cells per 8x8 tile), else 14 (one more wavefront per SIMD); 14 / 21: fixed.  Same results
