@@ -722,7 +722,7 @@ def main():
                        "parallelism": "single GPU" if world == 1 else
                                       (f"whole frames dealt round-robin to {world} ranks, grid replicated, no exchange" if frame_parallel else
                                        (f"row tiles of {TILE_ROWS} rows dealt cyclically to {world} ranks" if blocks is None else
-                                        f"{world} contiguous row blocks balanced by measured segments per row "
+                                        f"{world} contiguous row blocks balanced by measured segments per row, then by the GPU times the ranks took for them, at multiples of 8 rows "
                                         f"(rows per rank {[n for _, n in blocks]})") +
                                        ", grid replicated, one RCCL exchange per frame to rank 0"),
                        "segments_per_frame": S_total if not frame_parallel else stats["segments"],
