@@ -159,6 +159,9 @@ struct c5_context {
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     int fuse_setup = 0;     // build_records + entry_raster as one launch of interleaved workgroups: measured 0.119 ms against
                             // 0.047 + 0.047 ms for the two launches on the C3 frame (the raster inherits the records' 49 KB of LDS)
+    int cell_order = 1;     // "cell_order": c5_upload_grid keeps the cells in Morton order of their centroids (set BEFORE the upload)
+    std::vector<int32_t> cell_perm;  // device index -> the caller's (empty: the same)
+    int block_cull = 1;     // "block_cull": build_records judges whole workgroups by a sphere about their cells (a part of the rows only)
     int tile_flags = 1;     // "tile_flags": the raster marks the tiles that hold an entry, the walk looks there first (enqueue_frame)
     int cost_order = 1;     // "cost_order": rows of super-blocks start dearest first (by the last frame the host waited for)
     uint8_t sb_order[128] = {};
@@ -185,7 +188,7 @@ struct c5_context {
     double box_lo[3] = {0, 0, 0}, box_hi[3] = {0, 0, 0};  // the grid's bounding box in object space
     double alpha_floor = 0.0;  // smallest alpha of the grid that is >= DBL_EPSILON (+inf: none)
     int overlap_setup = 0;  // measured: 1.27 vs 1.26 ms/frame, the side stream buys nothing
-    DeviceBuffer px, py, pz, cell_vert, cell_adj, alpha, q, bface;
+    DeviceBuffer px, py, pz, cell_vert, cell_adj, alpha, q, bface, block_sphere;
     double alpha_top = 0.0;      // largest alpha of the grid (c5_upload_grid / c5_update_scalars)
     double edge_max = 0.0;       // longest edge of any cell: no view makes a cell longer along a ray
     double grid_diagonal = 0.0;  // of the grid's bounding box in object space: no rotation makes the grid longer along a ray
@@ -576,6 +579,9 @@ int enqueue_frame(c5_context* ctx, float2* out_dev, c5::FrameCounters* own_count
     g.q = ctx->q.as<double>();
     g.bface = ctx->bface.as<uint32_t>();
     g.xrec = fs.rec.as<c5::ExitRecord>();
+    g.rot = ctx->view;
+    // (whole workgroups of build_records judged by their cells' sphere: only where the rows are a part of the image)
+    g.block_sphere = (ctx->block_cull && im.n_local_rows > 0 && im.n_local_rows < im.res_y && ctx->block_sphere.ptr) ? ctx->block_sphere.as<double4>() : nullptr;
     // y band of the rows this context renders (one pixel of slack on both sides)
     if (im.n_local_rows > 0) {
         const int first = c5::global_row_of(im, 0), last = c5::global_row_of(im, im.n_local_rows - 1);
@@ -1359,11 +1365,64 @@ int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int3
             cell_vert = welded.data();
         }
     }
+    // "cell_order" (round 4): the cells are kept in Morton order of their centroids, whatever order the caller has them in
+    // - 256 consecutive cells are then a compact lump of the grid, which is what lets build_records drop whole workgroups
+    // by a sphere about their cells (GridView::block_sphere) and keeps a boundary face's record near its neighbours'.
+    // Nothing of it shows outside: images are bit-equal (a cell's own arithmetic does not know its number), and
+    // c5_update_scalars takes its arrays in the caller's order.  Not for grids that go to bin_sort_resolve (below).
+    std::vector<int32_t> perm;  // new index -> the caller's
+    std::vector<int32_t> ordered;
+    const int32_t* caller_cell_vert = cell_vert;
+    if (ctx->cell_order && n_cells >= 4096) {
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        std::vector<double> cen(static_cast<size_t>(3 * n_cells));
+        for (int64_t c = 0; c < n_cells; ++c)
+            for (int k = 0; k < 3; ++k) {
+                double m = 0.0;
+                for (int a = 0; a < 4; ++a) m += xyz[3 * static_cast<int64_t>(cell_vert[4 * c + a]) + k];
+                cen[static_cast<size_t>(3 * c + k)] = m;
+                lo[k] = std::fmin(lo[k], m);
+                hi[k] = std::fmax(hi[k], m);
+            }
+        auto spread = [](uint64_t v) {  // 10 bits -> every third bit
+            v &= 0x3ffull;
+            v = (v | (v << 16)) & 0x30000ffull;
+            v = (v | (v << 8)) & 0x300f00full;
+            v = (v | (v << 4)) & 0x30c30c3ull;
+            v = (v | (v << 2)) & 0x9249249ull;
+            return v;
+        };
+        std::vector<std::pair<uint64_t, int32_t>> keyed(static_cast<size_t>(n_cells));
+        for (int64_t c = 0; c < n_cells; ++c) {
+            uint64_t key = 0;
+            for (int k = 0; k < 3; ++k) {
+                const double span = hi[k] - lo[k];
+                const double t = span > 0.0 ? (cen[static_cast<size_t>(3 * c + k)] - lo[k]) / span * 1024.0 : 0.0;
+                key |= spread(static_cast<uint64_t>(std::fmin(std::fmax(t, 0.0), 1023.0))) << k;
+            }
+            keyed[static_cast<size_t>(c)] = {key, static_cast<int32_t>(c)};
+        }
+        std::sort(keyed.begin(), keyed.end());  // (ties by the caller's index: a total order, the same on every rank)
+        bool identity = true;
+        for (int64_t c = 0; c < n_cells && identity; ++c) identity = keyed[static_cast<size_t>(c)].second == c;
+        if (!identity) {
+            perm.resize(static_cast<size_t>(n_cells));
+            ordered.resize(static_cast<size_t>(4 * n_cells));
+            for (int64_t c = 0; c < n_cells; ++c) {
+                const int32_t from = keyed[static_cast<size_t>(c)].second;
+                perm[static_cast<size_t>(c)] = from;
+                for (int a = 0; a < 4; ++a) ordered[static_cast<size_t>(4 * c + a)] = cell_vert[4 * static_cast<int64_t>(from) + a];
+            }
+            cell_vert = ordered.data();
+        }
+    }
     std::vector<int32_t> adj;
     std::vector<uint32_t> bfaces;
     std::string err;
     bool conforming = true;
     if (!c5::build_face_adjacency(cell_vert, n_cells, n_pts, adj, bfaces, err)) {
+        cell_vert = caller_cell_vert;  // (bin_sort_resolve breaks ties of equal depths by the cells' order: the caller's stays)
+        perm.clear();
         if (err.find("range") != std::string::npos) return fail(ctx, C5_ERR_INVALID, "%s", err.c_str());
         // a face shared by more than two cells: no walk possible, the reference's own algorithm will do
         conforming = false;
@@ -1412,9 +1471,18 @@ int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int3
         for (size_t i = 0; i < bfaces.size(); ++i)
             adj_dev[static_cast<size_t>(bfaces[i] >> 2) * 4 + (bfaces[i] & 3u)] = -static_cast<int32_t>(i) - 2;
         C5_HIP(ctx, hipMemcpy(ctx->cell_adj.ptr, adj_dev.data(), cb * 16, hipMemcpyHostToDevice));
-        C5_HIP(ctx, hipMemcpy(ctx->alpha.ptr, alpha, cb * 8, hipMemcpyHostToDevice));
-        C5_HIP(ctx, hipMemcpy(ctx->q.ptr, q, cb * 8, hipMemcpyHostToDevice));
+        std::vector<double> a_dev, q_dev;
+        const double *a_src = alpha, *q_src = q;
+        if (!perm.empty()) {
+            a_dev.resize(cb);
+            q_dev.resize(cb);
+            for (size_t c = 0; c < cb; ++c) a_dev[c] = alpha[perm[c]], q_dev[c] = q[perm[c]];
+            a_src = a_dev.data(), q_src = q_dev.data();
+        }
+        C5_HIP(ctx, hipMemcpy(ctx->alpha.ptr, a_src, cb * 8, hipMemcpyHostToDevice));
+        C5_HIP(ctx, hipMemcpy(ctx->q.ptr, q_src, cb * 8, hipMemcpyHostToDevice));
     }
+    ctx->cell_perm = std::move(perm);
     if (!bfaces.empty())
         C5_HIP(ctx, hipMemcpy(ctx->bface.ptr, bfaces.data(), bfaces.size() * 4, hipMemcpyHostToDevice));
     {
@@ -1452,6 +1520,26 @@ int c5_upload_grid(c5_context* ctx, const double* xyz, int64_t n_pts, const int3
             }
     }
     ctx->edge_max = std::sqrt(edge2) * (1.0 + 1e-9);  // (the rotations round: a hair of margin)
+    {   // a sphere about every 256 consecutive cells (one workgroup of build_records): kernels.hpp: GridView::block_sphere
+        const int64_t n_blocks = (n_cells + 255) / 256;
+        std::vector<double> sph(static_cast<size_t>(4 * n_blocks), 0.0);
+        for (int64_t b = 0; b < n_blocks; ++b) {
+            double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (int64_t c = 256 * b; c < std::min<int64_t>(n_cells, 256 * (b + 1)); ++c)
+                for (int a = 0; a < 4; ++a) {
+                    const double* p = xyz + 3 * static_cast<int64_t>(cell_vert[4 * c + a]);
+                    for (int k = 0; k < 3; ++k) lo[k] = std::fmin(lo[k], p[k]), hi[k] = std::fmax(hi[k], p[k]);
+                }
+            double r2 = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                sph[static_cast<size_t>(4 * b + k)] = 0.5 * (lo[k] + hi[k]);
+                r2 += 0.25 * (hi[k] - lo[k]) * (hi[k] - lo[k]);
+            }
+            sph[static_cast<size_t>(4 * b + 3)] = std::sqrt(r2) * (1.0 + 1e-12);
+        }
+        C5_HIP(ctx, ctx->block_sphere.ensure(sph.size() * sizeof(double) + 32));
+        if (!sph.empty()) C5_HIP(ctx, hipMemcpy(ctx->block_sphere.ptr, sph.data(), sph.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     ctx->n_pts = n_pts;
     ctx->n_cells = n_cells;
     ctx->n_bfaces = static_cast<int64_t>(bfaces.size());
@@ -1469,8 +1557,16 @@ int c5_update_scalars(c5_context* ctx, const double* alpha, const double* q, int
     if (rc) return rc;
     C5_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (n_cells > 0) {
-        C5_HIP(ctx, hipMemcpy(ctx->alpha.ptr, alpha, static_cast<size_t>(n_cells) * 8, hipMemcpyHostToDevice));
-        C5_HIP(ctx, hipMemcpy(ctx->q.ptr, q, static_cast<size_t>(n_cells) * 8, hipMemcpyHostToDevice));
+        std::vector<double> a_dev, q_dev;
+        const double *a_src = alpha, *q_src = q;
+        if (!ctx->cell_perm.empty()) {  // (the device keeps the cells in its own order: c5_upload_grid, "cell_order")
+            a_dev.resize(static_cast<size_t>(n_cells));
+            q_dev.resize(static_cast<size_t>(n_cells));
+            for (size_t c = 0; c < static_cast<size_t>(n_cells); ++c) a_dev[c] = alpha[ctx->cell_perm[c]], q_dev[c] = q[ctx->cell_perm[c]];
+            a_src = a_dev.data(), q_src = q_dev.data();
+        }
+        C5_HIP(ctx, hipMemcpy(ctx->alpha.ptr, a_src, static_cast<size_t>(n_cells) * 8, hipMemcpyHostToDevice));
+        C5_HIP(ctx, hipMemcpy(ctx->q.ptr, q_src, static_cast<size_t>(n_cells) * 8, hipMemcpyHostToDevice));
     }
     ctx->alpha_top = 0.0;
     ctx->alpha_floor = INFINITY;
@@ -1718,6 +1814,10 @@ int c5_set_option(c5_context* ctx, const char* name, double value) {
         ctx->fuse_setup = static_cast<int>(value) != 0;
     } else if (n == "overlap_setup") {
         ctx->overlap_setup = static_cast<int>(value) != 0;
+    } else if (n == "cell_order") {
+        ctx->cell_order = static_cast<int>(value) != 0;
+    } else if (n == "block_cull") {
+        ctx->block_cull = static_cast<int>(value) != 0;
     } else if (n == "tile_flags") {
         ctx->tile_flags = static_cast<int>(value) != 0;
     } else if (n == "cost_order") {

@@ -21,6 +21,11 @@ struct GridView {  // device pointers of the persistent grid + per-view buffers
     ExitRecord* xrec = nullptr;  // fp64 walk: one 128-byte line per cell and view (exit candidates + optics)
     // only cells whose projected y-extent meets [cull_y_lo, cull_y_hi] can be reached by a ray of this context
     double cull_y_lo = 0, cull_y_hi = 0;
+    // ... and whole workgroups of build_records (256 consecutive cells) are judged first by a sphere about their cells
+    // (centre x, y, z and radius in the grid's own coordinates, made at upload; the view is a rigid motion): a context that
+    // renders an eighth of the rows does not look at the vertices of the other seven eighths' cells.  nullptr: not judged.
+    const double4* block_sphere = nullptr;
+    RotationList rot{};  // the frame's view (for the spheres' centres)
     SplitParams split{};  // "depth_split": build_records lists the cells that straddle a cutting plane (n_slabs > 1)
     // boundary-face records for entry_raster_rec (nullptr: none wanted), stamped bf_seq; which faces a ray enters through
     BFaceRecord* bfrec = nullptr;

@@ -43,6 +43,26 @@ template <bool SPLIT, bool BF>
 __device__ __forceinline__ void build_records_block(const GridView& g, double alpha_limit, int order, unsigned block,
                                                     Q4 (*s_rec)[64 * kRecPad]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (g.block_sphere) {  // (uniform) all of this workgroup's cells outside the context's rows?  (kernels.hpp)
+        const double4 s = g.block_sphere[block];
+        double cx = s.x, cy = s.y, cz = s.z;
+        for (int r = 0; r < g.rot.n; ++r) {  // tetra.cpp:44-62 on the centre (its rounding is covered by the margin below)
+            const double co = g.rot.cosv[r], si = g.rot.sinv[r];
+            if (g.rot.axis[r] == 0) {
+                const double y_old = cy;
+                cy = cy * co - cz * si;
+                cz = y_old * si + cz * co;
+            } else {
+                cx -= g.rot.x0[r];
+                const double x_old = cx;
+                cx = cx * co - cz * si;
+                cz = x_old * si + cz * co;
+                cx += g.rot.x0[r];
+            }
+        }
+        const double reach = s.w + 1e-9 * (s.w + fabs(cy) + 1.0);
+        if (cy + reach < g.cull_y_lo || cy - reach > g.cull_y_hi) return;
+    }
     const int64_t cell = block * static_cast<int64_t>(blockDim.x) + threadIdx.x;
     const int64_t wave_first = cell - lane;
     bool valid = cell < g.n_cells;
