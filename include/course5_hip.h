@@ -182,6 +182,11 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  wavefronts) start the rows of their image that hold the LONGEST rays first (by the last frame the caller
  *                  waited for) instead of top to bottom: a launch ends on whatever started last; 0: always top to bottom;
  *                  2: that order whatever the frame's size (experiments).  Same results.
+ *   "cell_order"   1 (default; read by c5_upload_grid: set it BEFORE the upload): the library keeps the cells in Morton order of
+ *                  their centroids, whatever order the caller has them in (grids of 4 096 cells and more that go to the
+ *                  walk); c5_update_scalars still takes its arrays in the caller's order.  Same results, bit for bit.
+ *   "block_cull"   1 (default): a context that renders a part of the image's rows judges every 256 consecutive cells by a
+ *                  sphere about them before it builds their per-view records; 0: cell by cell only.  Same results.
  *   "tile_flags"   1 (default): the entry raster marks the 8x8 pixel tiles a boundary face's box meets, and a wavefront of the
  *                  walk looks at its tile's mark before anything else (default tile shape, no solids); 0: every wavefront
  *                  reads its pixels' entry heads.  Same results.
