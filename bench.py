@@ -369,6 +369,7 @@ def main():
         # ... and cut again, twice, by what the ranks TOOK for those blocks (GPU time of a frame, HIP events): the model
         # misses what a segment costs where and what a share costs whatever its rows (sharding.time_weighted_costs;
         # `course --devices` does the same with the times of its probe frames)
+        ctx.set_option("stage_timing", 1)  # (the frame's GPU time comes from its stage events; off again below)
         for _ in range(2):
             buf = torch.zeros((ctx.local_rows, rx, 2), dtype=torch.float32, device=dev)
             mine = 0.0
@@ -387,6 +388,7 @@ def main():
                 break
             blocks = again
             ctx.set_row_range(*blocks[rank])
+        ctx.set_option("stage_timing", 0)
         return blocks
 
     def measure(rx, ry, steps, warmup, split, steadying):
