@@ -361,6 +361,8 @@ int main(int argc, char** argv) try {
                   << st.segments << " segments, " << st.covered_pixels << " covered pixels, " << st.solid_pixels
                   << " solid pixels" << std::endl;
     }
+    if (is_sweep)  // (the frames to come print no stage times: their events, 25 us per frame, are not recorded)
+        for (const auto& p : planes) p->stage_times(false);
 
     // sweep: the grid, its adjacency and the solids stay on the GPU(s); only rotation lists change.  This thread
     // works out the angles of frame k and deals it to the driver of plane k mod N; every driver issues its frames

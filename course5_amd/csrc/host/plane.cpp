@@ -483,8 +483,18 @@ void plane::set_views(const views_t& v) {
 
 void plane::start(frame_t& f) {
     const bool blocks = _ctx.size() > 1 && _layout == row_layout::blocks;
+    if (_stage_on.size() != _ctx.size()) _stage_on.assign(_ctx.size(), -1);
     for (std::size_t r = 0; r < _ctx.size(); ++r) {
         if (blocks) check(c5_set_option(_ctx[r], "row_costs", f.probe ? 1.0 : 0.0), "c5_set_option", r);
+        // (a probe frame, and the frames issued while one is in flight: read_row_costs reads the time of the LAST frame each
+        // device has completed)
+        bool probing = f.probe;
+        for (const frame_t& g : _flight) probing = probing || g.probe;
+        const int want_times = (_stage_times || probing) ? 1 : 0;
+        if (_stage_on[r] != want_times) {
+            check(c5_set_option(_ctx[r], "stage_timing", want_times), "c5_set_option", r);
+            _stage_on[r] = want_times;
+        }
         if (_exchange == exchange_mode::host) {
             check(c5_render_frame_rows_async(_ctx[r], f.image.get()), "find_intersections", r);
         } else {

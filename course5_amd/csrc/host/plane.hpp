@@ -119,6 +119,9 @@ public:
     // the rows [begin, begin + count) every device renders (blocks layout) — for logs and tests
     std::vector<std::pair<int, int>> row_blocks() const { return _blocks; }
     std::size_t rebalances() const { return _rebalances; }
+    // The library's per-stage GPU times (c5_stats::ms_*) come from six events per frame, 25 us of a 0.55-ms frame: a sweep
+    // that does not print them switches them off (probe frames of the blocks layout keep theirs: they time the blocks).
+    void stage_times(bool on) { _stage_times = on; }
 
 private:
     struct frame_t {
@@ -151,6 +154,8 @@ private:
     std::vector<char> _retry_seen;
     std::size_t _issued = 0, _rebalances = 0;
     bool _rebalance_due = false;
+    bool _stage_times = true;
+    std::vector<int> _stage_on;  // per device: what "stage_timing" was last set to (-1: not yet)
 };
 
 // {x_max, x_min, y_max, y_min} of the objects' transformed vertices: what the reference's plane uses when no
