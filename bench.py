@@ -446,6 +446,9 @@ def main():
             sweep["k"] = k0
             stats = ctx.stats()
             ctx.walk_kernel_ms(reset=True)
+            # (the timed region: the walk kernel is timed by HIP events around every 4th launch - two events cost 6 us of a
+            # 0.53-ms frame; the JSON says how many launches the average is taken over)
+            ctx.set_option("walk_timing", 4)
             for attempt in range(3):
                 if world > 1:
                     dist.barrier()
@@ -471,6 +474,7 @@ def main():
                 sweep["k"] = k0
             else:
                 raise SystemExit("frames kept being re-rendered inside the timed region")
+            ctx.set_option("walk_timing", 1)
             retries += pipe.retries
         el = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         seg = torch.tensor([stats["segments"], n_local * rx, retries], dtype=torch.int64, device=rdev)
@@ -680,6 +684,7 @@ def main():
             "traffic": hbm_bytes,
             "traffic_source": (pmc or {}).get("source"),
             "kernel_ms": round(walk_ms, 4), "launches": walk_launches,
+            "kernel_ms_sampling": "HIP events around every 4th launch of the timed region (two events cost 6 us of a frame)",
             "kernel_ms_rocprofv3": (pmc or {}).get("kernel_ms_rocprofv3"),
             "limiter": (pmc or {}).get("limiter"),
             "units": (pmc or {}).get("units"),

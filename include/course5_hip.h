@@ -239,7 +239,8 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  picked up by the abutting cell (the reference never looks at connectivity, object3d_base.cpp:37-42;
  *                  DESIGN.md section 5).  0 (testing): keyed at the face's own depth, as before round 3.
  *   "stage_timing" / "walk_timing"  0/1: record HIP events per stage (default 1: c5_stats::ms_* are those of the last frame
- *                  rendered with it on) / around walk_composite (default 0).  The six stage events cost 25 us of a 0.55-ms
+ *                  rendered with it on) / around walk_composite ("walk_timing" N: around
+ *                  every N-th launch; default 1, 0: off; two events cost 6 us when frames follow one another).  The six stage events cost 25 us of a 0.55-ms
  *                  frame when frames follow one another without a wait: a caller who renders a sweep switches them off. */
 int c5_set_option(c5_context* ctx, const char* name, double value);
 

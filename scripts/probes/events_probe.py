@@ -1,4 +1,4 @@
-"""Scratch probe: what the six stage events of a frame cost (frames back to back, wall clock)."""
+"""Scratch probe: what a frame's events cost (frames back to back, wall clock): the six stage events, the two around the walk."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -17,8 +17,9 @@ def wall(n=400):
     for _ in range(n): ctx.render_device(out.data_ptr())
     ctx.synchronize()
     return (time.perf_counter() - t0) * 1e3 / n
-res = {0: [], 1: []}
-for f in (1, 0, 0, 1, 1, 0):
-    ctx.set_option("stage_timing", f)
-    res[f].append(wall())
-print("stage_timing 1:", " ".join("%.4f" % v for v in res[1]), "| 0:", " ".join("%.4f" % v for v in res[0]))
+res = {}
+for st, wt in ((0, 0), (0, 1), (1, 0), (0, 0), (0, 1), (1, 0)):
+    ctx.set_option("stage_timing", st); ctx.set_option("walk_timing", wt)
+    res.setdefault((st, wt), []).append(wall())
+for k, v in res.items():
+    print("stage_timing %d walk_timing %d:" % k, " ".join("%.4f" % x for x in v))
