@@ -448,7 +448,8 @@ def main():
             ctx.walk_kernel_ms(reset=True)
             # (the timed region: the walk kernel is timed by HIP events around every 4th launch - two events cost 6 us of a
             # 0.53-ms frame; the JSON says how many launches the average is taken over)
-            ctx.set_option("walk_timing", 4)
+            walk_every = 4 if steps >= 200 else 1  # (a short region: every launch)
+            ctx.set_option("walk_timing", walk_every)
             for attempt in range(3):
                 if world > 1:
                     dist.barrier()
@@ -684,7 +685,7 @@ def main():
             "traffic": hbm_bytes,
             "traffic_source": (pmc or {}).get("source"),
             "kernel_ms": round(walk_ms, 4), "launches": walk_launches,
-            "kernel_ms_sampling": "HIP events around every 4th launch of the timed region (two events cost 6 us of a frame)",
+            "kernel_ms_sampling": "HIP events around every 4th launch of the timed region when it has 200 steps or more, else around every launch (two events cost 6 us of a frame)",
             "kernel_ms_rocprofv3": (pmc or {}).get("kernel_ms_rocprofv3"),
             "limiter": (pmc or {}).get("limiter"),
             "units": (pmc or {}).get("units"),
