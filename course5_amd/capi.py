@@ -130,6 +130,10 @@ class Context:
         if rc != C5_OK:
             raise C5Error(rc, self.lib.c5_last_error(None).decode())
         self.res_x = self.res_y = 0
+        # the library's instruments are off by default (they cost 5 % of a frame); tests and scripts read stats()["ms_*"] and
+        # walk_kernel_ms() everywhere, so this wrapper switches them on - bench.py switches the stage events off again
+        self.set_option("stage_timing", 1)
+        self.set_option("walk_timing", 1)
 
     def close(self):
         if getattr(self, "handle", None) and self.handle.value:

@@ -227,8 +227,10 @@ struct c5_context {
     int band_rows = 0;
     int order = 0;
     int lds_stage = 2;
-    int stage_timing = 1;
-    int walk_timing = 1;
+    // instruments, off unless asked for: the six stage events cost 21-25 us of a 0.52-ms frame when frames follow one another
+    // without a wait, the two around the walk 6 (profiles/experiments.md)
+    int stage_timing = 0;
+    int walk_timing = 0;
     unsigned walk_seq = 0;
 
     // events

@@ -238,10 +238,10 @@ int c5_set_alpha_limit(c5_context* ctx, double alpha_limit);
  *                  partner with the same three points — hanging nodes: a coarse face against several fine ones — is
  *                  picked up by the abutting cell (the reference never looks at connectivity, object3d_base.cpp:37-42;
  *                  DESIGN.md section 5).  0 (testing): keyed at the face's own depth, as before round 3.
- *   "stage_timing" / "walk_timing"  0/1: record HIP events per stage (default 1: c5_stats::ms_* are those of the last frame
- *                  rendered with it on) / around walk_composite ("walk_timing" N: around
- *                  every N-th launch; default 1, 0: off; two events cost 6 us when frames follow one another).  The six stage events cost 25 us of a 0.55-ms
- *                  frame when frames follow one another without a wait: a caller who renders a sweep switches them off. */
+ *   "stage_timing" / "walk_timing"  record HIP events per stage (0 / 1; c5_stats::ms_* are those of the last frame rendered
+ *                  with it on) / around walk_composite ("walk_timing" N: around every N-th launch, for c5_walk_kernel_ms).
+ *                  Both default to 0: the six stage events cost 21-25 us of a 0.52-ms frame when frames follow one another
+ *                  without a wait, the two around the walk 6. */
 int c5_set_option(c5_context* ctx, const char* name, double value);
 
 /* --- render ---------------------------------------------------------------------------------- */
